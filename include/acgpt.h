@@ -1,0 +1,190 @@
+/*
+ * acgpt.h — C ABI of the MI355X-native path-trace hot path.
+ *
+ * This is the drop-in boundary for the render path of the reference's
+ * PathTracer_Optix/PathTracerMain.cpp: every entry point below replaces one of
+ * the plain functions that file calls over its `PathTracerState&`
+ * (PathTracerMain.cpp:71-93).  The reference has no FFI layer of its own; these
+ * are the symbols a cgo / JNI / ctypes / C++ binding for that path would bind.
+ *
+ * Conventions
+ *   - every call returns 0 on success, non-zero on failure; the message is
+ *     available from pt_last_error() (the reference throws sutil::Exception
+ *     from CUDA_CHECK / OPTIX_CHECK, sutil/Exception.h:82-112; the C++ wrapper
+ *     in acgpathtracing_amd/host re-throws to keep that convention).
+ *   - the context owns every device allocation it makes; host arrays are
+ *     borrowed for the duration of the call only.
+ *   - a context is single-threaded (the reference is: one host thread, one
+ *     stream, launch-then-sync per frame, PathTracerMain.cpp:184-210).
+ *   - image row 0 is the BOTTOM row (pathTracerPrograms.cu:782-783 with
+ *     sutil/Camera.cpp:34-45: V points up).
+ *   - there is NO CPU fallback behind this ABI: without a HIP device
+ *     pt_create() fails.
+ */
+#ifndef ACGPT_H
+#define ACGPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pt_ctx pt_ctx;
+
+typedef struct pt_float3 { float x, y, z; } pt_float3;
+
+/* BSDFType, PathTracer_Optix/TinyObjWrapper.h:27-31 */
+enum { PT_BSDF_DIFFUSE = 0, PT_BSDF_METALLIC = 1, PT_BSDF_REFRACTION = 2 };
+
+/* Material, PathTracer_Optix/TinyObjWrapper.h:33-40 (40 bytes, same field order).
+ * roughness and metallic are carried but ignored by the shading, exactly as in
+ * the reference (pathTracerPrograms.cu:879-880). */
+typedef struct pt_material {
+    pt_float3 diffuse;
+    pt_float3 emission;
+    float     roughness;
+    float     metallic;
+    float     ior;
+    int32_t   bsdfType;
+} pt_material;
+
+/* AreaLight, PathTracer_Optix/pathTracer.h:77-83 (60 bytes). */
+typedef struct pt_area_light {
+    pt_float3 corner;
+    pt_float3 v1;
+    pt_float3 v2;
+    pt_float3 normal;
+    pt_float3 emission;
+} pt_area_light;
+
+/* PathTraceParams, PathTracer_Optix/pathTracer.h:85-108 — field for field,
+ * sizeof == 168 on LP64 like the reference's.  accumulationBuffer (float4[w*h],
+ * linear radiance, alpha 1) and frameBuffer (uchar4[w*h], sRGB) are DEVICE
+ * pointers supplied by the caller, as in the reference (PathTracerMain.cpp:
+ * 145-148, 186-188); frameBuffer may also be pinned host memory mapped into
+ * the device (the ZERO_COPY mode of sutil/CUDAOutputBuffer.h:45-51).
+ * `handle` is the value returned by pt_scene_handle() (the reference stores
+ * the OptixTraversableHandle there, PathTracerMain.cpp:159). */
+typedef struct pt_params {
+    uint32_t      currentFrameIdx;
+    float*        accumulationBuffer;
+    uint8_t*      frameBuffer;
+    uint32_t      width;
+    uint32_t      height;
+    uint32_t      samplesPerPixel;
+    uint32_t      maxDepth;
+    pt_float3     cameraEye;
+    pt_float3     cameraU;
+    pt_float3     cameraV;
+    pt_float3     cameraW;
+    pt_area_light areaLight;
+    uint64_t      handle;
+    uint8_t       useDirectLighting;     /* bool */
+    uint8_t       useImportanceSampling; /* bool */
+} pt_params;
+
+/* Counters of the most recent pt_launch (the reference counts nothing; Mray/s
+ * is defined in SURVEY.md §8d as radiance segments + shadow rays per second). */
+typedef struct pt_stats {
+    uint64_t radiance_rays;   /* closest-hit segments traced                  */
+    uint64_t shadow_rays;     /* next-event occlusion rays traced             */
+    uint64_t paths;           /* camera paths started (= pixels * spp)        */
+    float    kernel_ms;       /* megakernel duration, HIP events on its stream*/
+    float    launch_ms;       /* pt_launch entry -> synchronised return       */
+    uint32_t pixels;          /* pixels this launch rendered (tile partition) */
+    uint32_t reserved;
+} pt_stats;
+
+/* What the on-device LBVH build produced. */
+typedef struct pt_bvh_info {
+    uint32_t n_tris;
+    uint32_t n_nodes;         /* internal nodes (n_tris - 1, or 1 if n_tris==1) */
+    uint32_t max_depth;       /* longest root->leaf path, in internal nodes   */
+    uint32_t stack_entries;   /* per-lane traversal stack entries reserved    */
+    float    scene_lo[3];
+    float    scene_hi[3];
+    float    build_ms;        /* morton + sort + hierarchy + refit, device ms */
+    uint32_t node_bytes;      /* bytes of the traversal node array            */
+    uint32_t tri_bytes;       /* bytes of the leaf triangle array             */
+} pt_bvh_info;
+
+/* ---- lifetime -------------------------------------------------------------
+ * pt_create   <- createDeviceContext(), PathTracerMain.cpp:240-258, plus
+ *                createModule/ProgramGroups/Pipeline, :400-539 (nothing to JIT:
+ *                the code object is built ahead of time for gfx950).
+ * pt_destroy  <- CleanAllTheThings(), PathTracerMain.cpp:629-646.            */
+int         pt_create(pt_ctx** out, int device_id);
+void        pt_destroy(pt_ctx* ctx);
+const char* pt_last_error(pt_ctx* ctx);   /* ctx may be NULL: last global error */
+
+/* ---- scene ------------------------------------------------------------------
+ * pt_set_scene <- buildTheAccelarationStructure(), PathTracerMain.cpp:260-398
+ *                 + createShaderBindingTable(), :544-627.
+ * verts_xyzw: n_verts * 4 floats (w ignored; stride 16 B as :314);
+ * idx: n_tris * 3 vertex indices; mat_ids: one per triangle (the reference's
+ * sbtIndexOffsetBuffer, :325-328); mats: n_mats records.
+ * A material id >= n_mats is an error (the reference would index past its SBT).
+ * Builds the LBVH on the device; replaces any previous scene.               */
+int      pt_set_scene(pt_ctx* ctx,
+                      const float* verts_xyzw, size_t n_verts,
+                      const uint32_t* idx, size_t n_tris,
+                      const uint32_t* mat_ids,
+                      const pt_material* mats, size_t n_mats);
+uint64_t pt_scene_handle(pt_ctx* ctx);
+int      pt_get_bvh_info(pt_ctx* ctx, pt_bvh_info* out);
+
+/* ---- the hot call -------------------------------------------------------------
+ * pt_launch <- LaunchCurrentFrame(), PathTracerMain.cpp:184-210: consumes a
+ * PathTraceParams by value, runs the megakernel over width x height pixels and
+ * returns synchronised (CUDA_SYNC_CHECK, :209).  Progressive accumulation
+ * follows pathTracerPrograms.cu:803-811 (running mean over currentFrameIdx).
+ * maxDepth outside [1,28] and samplesPerPixel == 0 are errors
+ * (PathTracerMain.cpp:42, 122-128; the do{}while(--i) at
+ * pathTracerPrograms.cu:727,780 requires spp >= 1).                           */
+int pt_launch(pt_ctx* ctx, const pt_params* params);
+
+/* Multi-GPU pixel partition: this context renders only the pixels that
+ * sutil/WorkDistribution.h:50-81 assigns to `rank` of `world` (interleaved 8x4
+ * tiles, rotated per strip row); other pixels of the buffers are left
+ * untouched.  world == 1 (the default) renders everything.                   */
+int pt_set_partition(pt_ctx* ctx, int rank, int world);
+
+/* Launch geometry override (0 = automatic): persistent workgroups per CU. */
+int pt_set_tuning(pt_ctx* ctx, int blocks_per_cu, int reserved);
+
+/* Stream the launches are enqueued on (a hipStream_t, e.g. torch's current
+ * stream); NULL restores the context's own stream (PathTracerMain.cpp:161). */
+int pt_set_stream(pt_ctx* ctx, void* hip_stream);
+int pt_get_stats(pt_ctx* ctx, pt_stats* out);
+
+/* ---- queries used by the parity tests ------------------------------------------
+ * rays: n records of 8 floats (origin xyz, direction xyz, tmin, tmax), HOST.
+ * closest: t_out[i] = hit distance or -1, prim_out[i] = triangle index (in the
+ * caller's index-buffer order) or 0xFFFFFFFF; interval is open (tmin, tmax),
+ * two-sided, ties -> lowest triangle index.  any: hit_out[i] = 1 if any
+ * triangle is hit inside the interval (traceOcclusion, pathTracerPrograms.cu:
+ * 651-684).                                                                    */
+int pt_trace_closest(pt_ctx* ctx, const float* rays, size_t n, float* t_out, uint32_t* prim_out);
+int pt_trace_any(pt_ctx* ctx, const float* rays, size_t n, uint8_t* hit_out);
+/* Sorted (morton, triangle) pairs of the last build, HOST outputs of n_tris. */
+int pt_read_morton(pt_ctx* ctx, uint32_t* codes_sorted, uint32_t* prims_sorted);
+
+/* ---- device memory helpers for bindings that have no HIP runtime of their own
+ * (the reference app calls cudaMalloc/cudaMemcpy directly, :145-148).         */
+int pt_device_malloc(pt_ctx* ctx, void** out, size_t bytes);
+int pt_device_free(pt_ctx* ctx, void* ptr);
+int pt_device_memset(pt_ctx* ctx, void* ptr, int value, size_t bytes);
+int pt_copy_to_host(pt_ctx* ctx, void* dst_host, const void* src_device, size_t bytes);
+int pt_copy_to_device(pt_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);
+int pt_host_malloc_mapped(pt_ctx* ctx, void** host_out, void** device_out, size_t bytes);
+int pt_host_free_mapped(pt_ctx* ctx, void* host_ptr);
+
+/* Version of this ABI. */
+uint32_t pt_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACGPT_H */

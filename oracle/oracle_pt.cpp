@@ -1,0 +1,771 @@
+/*
+ * oracle_pt.cpp — CPU restatement of the reference's per-pixel path-trace launch.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load this library, and only as the checker /
+ * the timed CPU baseline.  Nothing under acgpathtracing_amd/ links or calls it.
+ *
+ * What is restated, and from where (all paths relative to /root/reference):
+ *   tea<4>, lcg, rnd                    cuda/random.h:31-46, 49-55, 64-67
+ *   float3 algebra                      sutil/vec_math.h:378-570 (operation order kept:
+ *                                       a/s = a*(1/s), normalize = v*(1/sqrt(dot)), ...)
+ *   make_color / toSRGB / quantize      cuda/helpers.h:35-62
+ *   refract                             cuda/helpers.h:107-137
+ *   Camera::UVWFrame                    sutil/Camera.cpp:34-45
+ *   __raygen__rg                        PathTracer_Optix/pathTracerPrograms.cu:707-816
+ *   __closesthit__diffuse__ch           PathTracer_Optix/pathTracerPrograms.cu:866-1031
+ *   __miss__ms                          PathTracer_Optix/pathTracerPrograms.cu:833-847
+ *   OrthonormalBasis, *_sample_hemisphere, sampleGGX, fresnelSchlickConductor,
+ *   FrDielectric, traceOcclusion        same file :54-85, :341-380, :455-476, :494-510,
+ *                                       :534-559, :651-684
+ *   StaticWorkDistribution              sutil/WorkDistribution.h:50-81
+ *
+ * PARITY PINNING.  cuda/random.h, cuda/helpers.h, sutil/vec_math.h, sutil/Camera.cpp
+ * and PathTracer_Optix/TinyObjWrapper.cpp compile here from where they lie (recipe:
+ * oracle/Makefile -> oracle/_ref/libref.so) and this restatement is checked against
+ * them function by function (tests/test_oracle_vs_ref.py, fixtures in tests/golden/).
+ * pathTracerPrograms.cu itself needs <optix.h>, which this image does not have, so the
+ * three OptiX programs are UNBUILDABLE here and the reference ships no test or golden
+ * vector for them: for the raygen/closest-hit/miss glue, PARITY IS UNPINNED — it is a
+ * line-by-line restatement with the citations above, nothing stronger.
+ *
+ * What the reference does NOT define and this file therefore defines (the reference
+ * delegates it to OptiX's built-in triangle GAS, pathTracerPrograms.cu:600-613):
+ *   ray/triangle test  tri_test() below: Moeller-Trumbore, two-sided, fused multiply-adds
+ *                      exactly where written, one IEEE division; open interval (tmin,tmax).
+ *   closest hit        smallest t over all triangles; equal t -> lowest triangle index.
+ *   occlusion          any triangle hit inside (tmin,tmax) occludes.
+ * The GPU kernels must reproduce exactly these three definitions bit for bit.
+ *
+ * Build: see oracle/Makefile.  -ffp-contract=off is REQUIRED (the only fused operations
+ * are the explicit __builtin_fmaf calls).
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include <math.h>
+#include <string.h>
+#include <stdlib.h>
+#include <atomic>
+#include <thread>
+#include <vector>
+#include <algorithm>
+#include <chrono>
+
+#include "../include/acgpt.h"   /* POD layouts of the boundary only (no product code) */
+
+#define ORC_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+/* ---------------------------------------------------------------- float3 ---- */
+struct f3 { float x, y, z; };
+static inline f3 mk(float x, float y, float z) { f3 r = {x, y, z}; return r; }
+static inline f3 mk(float s) { return mk(s, s, s); }
+static inline f3 mk(const pt_float3& p) { return mk(p.x, p.y, p.z); }
+static inline f3 operator-(const f3& a) { return mk(-a.x, -a.y, -a.z); }
+static inline f3 operator+(const f3& a, const f3& b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline f3 operator-(const f3& a, const f3& b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline f3 operator*(const f3& a, const f3& b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline f3 operator*(const f3& a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+static inline f3 operator*(float s, const f3& a) { return mk(s * a.x, s * a.y, s * a.z); }
+static inline f3 operator/(const f3& a, const f3& b) { return mk(a.x / b.x, a.y / b.y, a.z / b.z); }
+/* vec_math.h:483-487: division by a scalar multiplies by the reciprocal */
+static inline f3 operator/(const f3& a, float s) { float inv = 1.0f / s; return a * inv; }
+static inline void operator+=(f3& a, const f3& b) { a.x += b.x; a.y += b.y; a.z += b.z; }
+static inline void operator*=(f3& a, const f3& b) { a.x *= b.x; a.y *= b.y; a.z *= b.z; }
+static inline void operator*=(f3& a, float s) { a.x *= s; a.y *= s; a.z *= s; }
+/* vec_math.h:527-530 */
+static inline float dot(const f3& a, const f3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+/* vec_math.h:533-536 */
+static inline f3 cross(const f3& a, const f3& b)
+{ return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+/* vec_math.h:539-542 */
+static inline float length(const f3& v) { return sqrtf(dot(v, v)); }
+/* vec_math.h:545-549 */
+static inline f3 normalize(const f3& v) { float invLen = 1.0f / sqrtf(dot(v, v)); return v * invLen; }
+/* vec_math.h:558-561 */
+static inline f3 reflect(const f3& i, const f3& n) { return i - 2.0f * n * dot(n, i); }
+/* vec_math.h:567-570 */
+static inline f3 faceforward(const f3& n, const f3& i, const f3& nref) { return n * copysignf(1.0f, dot(i, nref)); }
+/* vec_math.h:500-503 */
+static inline f3 lerp(const f3& a, const f3& b, float t) { return a + t * (b - a); }
+/* vec_math.h:119-122 */
+static inline float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }
+
+static const float kPIf = 3.14159265358979323846f;   /* M_PIf, vec_math.h:43-45 */
+
+/* ------------------------------------------------------------------ PRNG ---- */
+/* cuda/random.h:31-46 */
+static inline uint32_t tea4(uint32_t val0, uint32_t val1)
+{
+    uint32_t v0 = val0, v1 = val1, s0 = 0;
+    for (uint32_t n = 0; n < 4; n++) {
+        s0 += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    return v0;
+}
+/* cuda/random.h:49-55 */
+static inline uint32_t lcg(uint32_t& prev)
+{
+    prev = 1664525u * prev + 1013904223u;
+    return prev & 0x00FFFFFFu;
+}
+/* cuda/random.h:64-67 */
+static inline float rnd(uint32_t& prev) { return (float)lcg(prev) / (float)0x01000000; }
+
+/* ------------------------------------------------------------ make_color ---- */
+/* cuda/helpers.h:35-44 */
+static inline f3 toSRGB(const f3& c)
+{
+    float invGamma = 1.0f / 2.4f;
+    f3 powed = mk(powf(c.x, invGamma), powf(c.y, invGamma), powf(c.z, invGamma));
+    return mk(c.x < 0.0031308f ? 12.92f * c.x : 1.055f * powed.x - 0.055f,
+              c.y < 0.0031308f ? 12.92f * c.y : 1.055f * powed.y - 0.055f,
+              c.z < 0.0031308f ? 12.92f * c.z : 1.055f * powed.z - 0.055f);
+}
+/* cuda/helpers.h:51-56 */
+static inline uint8_t quantizeUnsigned8Bits(float x)
+{
+    x = clampf(x, 0.0f, 1.0f);
+    unsigned v = (unsigned)(x * 256.0f);
+    return (uint8_t)(v < 255u ? v : 255u);
+}
+/* cuda/helpers.h:58-63 */
+static inline void make_color(const f3& c, uint8_t out[4])
+{
+    f3 cl = mk(clampf(c.x, 0.0f, 1.0f), clampf(c.y, 0.0f, 1.0f), clampf(c.z, 0.0f, 1.0f));
+    f3 srgb = toSRGB(cl);
+    out[0] = quantizeUnsigned8Bits(srgb.x);
+    out[1] = quantizeUnsigned8Bits(srgb.y);
+    out[2] = quantizeUnsigned8Bits(srgb.z);
+    out[3] = 255u;
+}
+
+/* --------------------------------------------------------------- refract ---- */
+/* cuda/helpers.h:107-137 */
+static inline bool refract(f3& r, const f3& i, const f3& n, float ior)
+{
+    f3 nn = n;
+    float negNdotV = dot(i, nn);
+    float eta;
+    if (negNdotV > 0.0f) { eta = ior; nn = -n; negNdotV = -negNdotV; }
+    else                 { eta = 1.f / ior; }
+    const float k = 1.f - eta * eta * (1.f - negNdotV * negNdotV);
+    if (k < 0.0f) { r = mk(0.f); return false; }
+    r = normalize(eta * i - (eta * negNdotV + sqrtf(k)) * nn);
+    return true;
+}
+
+/* ------------------------------------------------- sampling / BSDF pieces ---- */
+/* pathTracerPrograms.cu:54-85 */
+struct OrthonormalBasis {
+    f3 m_tangent, m_binormal, m_normal;
+    explicit OrthonormalBasis(const f3& normal)
+    {
+        m_normal = normal;
+        if (fabsf(m_normal.x) > fabsf(m_normal.z)) {
+            m_binormal.x = -m_normal.y; m_binormal.y = m_normal.x; m_binormal.z = 0;
+        } else {
+            m_binormal.x = 0; m_binormal.y = -m_normal.z; m_binormal.z = m_normal.y;
+        }
+        m_binormal = normalize(m_binormal);
+        m_tangent = cross(m_binormal, m_normal);
+    }
+    void inverse_transform(f3& p) const { p = p.x * m_tangent + p.y * m_binormal + p.z * m_normal; }
+};
+/* pathTracerPrograms.cu:341-353 */
+static inline void cosine_sample_hemisphere(float eta1, float eta2, f3& p)
+{
+    const float theta = acosf(sqrtf(eta1));
+    const float phi = 2.0f * kPIf * eta2;
+    p.x = sinf(theta) * cosf(phi);
+    p.y = sinf(theta) * sinf(phi);
+    p.z = cosf(theta);
+}
+/* pathTracerPrograms.cu:368-380 (theta is computed and unused there) */
+static inline void uniform_sample_hemisphere(float u1, float u2, f3& wi)
+{
+    const float phi = 2.0f * kPIf * u2;
+    wi.x = cosf(phi) * sqrtf(1 - u1 * u1);
+    wi.y = sinf(phi) * sqrtf(1 - u1 * u1);
+    wi.z = u1;
+}
+/* pathTracerPrograms.cu:455-476 (the clamp at :458 discards its result) */
+static inline f3 sampleGGX(float u1, float u2, float roughness, const f3& N)
+{
+    float phi = 2.0f * kPIf * u1;
+    float cosTheta = sqrtf((1.0f - u2) / (1.0f + (roughness * roughness - 1.0f) * u2));
+    float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+    f3 H = mk(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta);
+    /* :470 `abs(N.z) < 0.999`: nvcc device code takes the float overload; the
+       comparison is in double */
+    f3 up = (double)fabsf(N.z) < 0.999 ? mk(0, 0, 1) : mk(1, 0, 0);
+    f3 tangent = normalize(cross(up, N));
+    f3 bitangent = cross(N, tangent);
+    f3 sampleDir = H.x * tangent + H.y * bitangent + H.z * N;
+    return normalize(sampleDir);
+}
+/* pathTracerPrograms.cu:494-510 */
+static inline f3 fresnelSchlickConductor(float cosTheta, f3 eta, f3 k)
+{
+    f3 eta2 = eta * eta;
+    f3 k2 = k * k;
+    f3 c2 = mk(cosTheta * cosTheta);
+    f3 t1 = eta2 - k2 - c2;
+    f3 a2plusb2 = mk(sqrtf(t1.x * t1.x + 4 * eta2.x * k2.x),
+                     sqrtf(t1.y * t1.y + 4 * eta2.y * k2.y),
+                     sqrtf(t1.z * t1.z + 4 * eta2.z * k2.z));
+    f3 t2 = a2plusb2 + c2;
+    f3 Rs = (t2 - 2 * eta * cosTheta + c2) / (t2 + 2 * eta * cosTheta + c2);
+    f3 Rp = Rs * (t2 - 2 * eta * cosTheta + mk(1)) / (t2 + 2 * eta * cosTheta + mk(1));
+    return (Rs + Rp) * 0.5f;
+}
+/* pathTracerPrograms.cu:534-559 */
+static inline float FrDielectric(float cosThetaI, float etaI, float etaT)
+{
+    cosThetaI = clampf(cosThetaI, -1.0f, 1.0f);
+    bool entering = cosThetaI > 0.0f;
+    if (!entering) { float t = etaI; etaI = etaT; etaT = t; cosThetaI = fabsf(cosThetaI); }
+    float sinThetaI = sqrtf(fmaxf(0.0f, 1.0f - cosThetaI * cosThetaI));
+    float sinThetaT = etaI / etaT * sinThetaI;
+    if (sinThetaT >= 1.0f) return 1.0f;
+    float cosThetaT = sqrtf(fmaxf(0.0f, 1.0f - sinThetaT * sinThetaT));
+    float rParl = ((etaT * cosThetaI) - (etaI * cosThetaT)) / ((etaT * cosThetaI) + (etaI * cosThetaT));
+    float rPerp = ((etaI * cosThetaI) - (etaT * cosThetaT)) / ((etaI * cosThetaI) + (etaT * cosThetaT));
+    return (rParl * rParl + rPerp * rPerp) / 2.0f;
+}
+/* pathTracerPrograms.cu:256-264 */
+static inline float safeDivide(float a, float b) { return b == 0.0f ? 0.0f : a / b; }
+static inline f3 safeDivide(f3 a, float b) { return mk(safeDivide(a.x, b), safeDivide(a.y, b), safeDivide(a.z, b)); }
+
+/* ------------------------------------------------- ray / triangle (OURS) ---- */
+static inline float dot_fma(const f3& a, const f3& b)
+{ return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+static inline f3 cross_fma(const f3& a, const f3& b)
+{
+    return mk(__builtin_fmaf(a.y, b.z, -(a.z * b.y)),
+              __builtin_fmaf(a.z, b.x, -(a.x * b.z)),
+              __builtin_fmaf(a.x, b.y, -(a.y * b.x)));
+}
+/* The triangle test every intersector in this repository must reproduce bit for bit. */
+static inline bool tri_test(const f3& o, const f3& d, const f3& v0, const f3& e1, const f3& e2,
+                            float tmin, float tmax, float& t_out)
+{
+    f3 p = cross_fma(d, e2);
+    float det = dot_fma(e1, p);
+    f3 s = o - v0;
+    float U = dot_fma(s, p);
+    f3 q = cross_fma(s, e1);
+    float V = dot_fma(d, q);
+    float T = dot_fma(e2, q);
+    if (det < 0.0f) { det = -det; U = -U; V = -V; T = -T; }
+    if (!(det > 0.0f)) return false;
+    if (U < 0.0f || V < 0.0f || U + V > det) return false;
+    float t = T / det;
+    if (!(t > tmin && t < tmax)) return false;
+    t_out = t;
+    return true;
+}
+
+/* ------------------------------------------------------------------ scene ---- */
+struct Tri { f3 v0, e1, e2; };
+struct BNode { float lo[3], hi[3]; uint32_t left, right, first, count; };  /* count>0: leaf */
+
+struct Scene {
+    std::vector<Tri> tris;
+    std::vector<uint32_t> mat_ids;
+    std::vector<pt_material> mats;
+    std::vector<BNode> nodes;
+    std::vector<uint32_t> order;   /* leaf triangle order */
+};
+
+static void tri_bounds(const Tri& t, float lo[3], float hi[3])
+{
+    f3 v1 = t.v0 + t.e1, v2 = t.v0 + t.e2;   /* slightly off the original v1/v2: padded below */
+    const float* a = &t.v0.x; const float* b = &v1.x; const float* c = &v2.x;
+    for (int k = 0; k < 3; k++) {
+        lo[k] = fminf(a[k], fminf(b[k], c[k]));
+        hi[k] = fmaxf(a[k], fmaxf(b[k], c[k]));
+        float pad = 1e-5f * fmaxf(1.0f, fmaxf(fabsf(lo[k]), fabsf(hi[k])));
+        lo[k] -= pad; hi[k] += pad;
+    }
+}
+
+/* Median-split BVH (its own builder: results do not depend on the tree as long as the
+ * box test is conservative, which the padded boxes + widened slab test guarantee; the
+ * tests check it against brute force). */
+static uint32_t build_rec(Scene& sc, std::vector<float>& lo, std::vector<float>& hi,
+                          std::vector<f3>& cen, uint32_t first, uint32_t count)
+{
+    uint32_t me = (uint32_t)sc.nodes.size();
+    sc.nodes.push_back(BNode());
+    float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = first; i < first + count; i++) {
+        uint32_t t = sc.order[i];
+        const float* c = &cen[t].x;
+        for (int k = 0; k < 3; k++) {
+            blo[k] = fminf(blo[k], lo[3 * t + k]); bhi[k] = fmaxf(bhi[k], hi[3 * t + k]);
+            clo[k] = fminf(clo[k], c[k]); chi[k] = fmaxf(chi[k], c[k]);
+        }
+    }
+    BNode n; memcpy(n.lo, blo, 12); memcpy(n.hi, bhi, 12);
+    n.left = n.right = 0; n.first = first; n.count = 0;
+    int axis = 0; float ext = chi[0] - clo[0];
+    for (int k = 1; k < 3; k++) if (chi[k] - clo[k] > ext) { ext = chi[k] - clo[k]; axis = k; }
+    if (count <= 4 || !(ext > 0.0f)) { n.count = count; sc.nodes[me] = n; return me; }
+    uint32_t mid = first + count / 2;
+    std::nth_element(sc.order.begin() + first, sc.order.begin() + mid, sc.order.begin() + first + count,
+                     [&](uint32_t a, uint32_t b) {
+                         float ca = (&cen[a].x)[axis], cb = (&cen[b].x)[axis];
+                         return ca < cb || (ca == cb && a < b);
+                     });
+    n.left = build_rec(sc, lo, hi, cen, first, mid - first);
+    n.right = build_rec(sc, lo, hi, cen, mid, first + count - mid);
+    sc.nodes[me] = n;
+    return me;
+}
+
+static void build_bvh(Scene& sc)
+{
+    size_t n = sc.tris.size();
+    std::vector<float> lo(3 * n), hi(3 * n);
+    std::vector<f3> cen(n);
+    sc.order.resize(n);
+    for (size_t i = 0; i < n; i++) {
+        tri_bounds(sc.tris[i], &lo[3 * i], &hi[3 * i]);
+        cen[i] = mk(0.5f * (lo[3 * i] + hi[3 * i]), 0.5f * (lo[3 * i + 1] + hi[3 * i + 1]), 0.5f * (lo[3 * i + 2] + hi[3 * i + 2]));
+        sc.order[i] = (uint32_t)i;
+    }
+    sc.nodes.clear();
+    if (n) build_rec(sc, lo, hi, cen, 0, (uint32_t)n);
+}
+
+/* Conservative slab test: far distance widened (Ize, "Robust BVH Ray Traversal", 2013);
+ * NaNs from 0*inf are dropped by fminf/fmaxf, which only ever widens the interval. */
+static inline bool box_test(const BNode& b, const f3& o, const f3& inv, float tmin, float tmax)
+{
+    float t0 = tmin, t1 = tmax;
+    const float* oo = &o.x; const float* ii = &inv.x;
+    for (int k = 0; k < 3; k++) {
+        float a = (b.lo[k] - oo[k]) * ii[k];
+        float c = (b.hi[k] - oo[k]) * ii[k];
+        float near = fminf(a, c), far = fmaxf(a, c);
+        far *= 1.0000004f;
+        t0 = fmaxf(t0, near); t1 = fminf(t1, far);   /* fmaxf/fminf ignore a NaN operand */
+    }
+    return t0 <= t1;
+}
+
+struct Hit { float t; uint32_t prim; };
+
+static inline void closest_brute(const Scene& sc, const f3& o, const f3& d, float tmin, float tmax, Hit& h)
+{
+    h.t = tmax; h.prim = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < sc.tris.size(); i++) {
+        float t;
+        /* strict '<' on ascending i keeps the lowest index among equal t */
+        if (tri_test(o, d, sc.tris[i].v0, sc.tris[i].e1, sc.tris[i].e2, tmin, tmax, t) && t < h.t) { h.t = t; h.prim = i; }
+    }
+}
+
+static inline void closest_bvh(const Scene& sc, const f3& o, const f3& d, float tmin, float tmax, Hit& h)
+{
+    h.t = tmax; h.prim = 0xFFFFFFFFu;
+    if (sc.nodes.empty()) return;
+    f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    uint32_t stack[128]; int sp = 0; stack[sp++] = 0;
+    while (sp) {
+        const BNode& n = sc.nodes[stack[--sp]];
+        if (!box_test(n, o, inv, tmin, h.t)) continue;    /* t0 <= best keeps equal-t candidates */
+        if (n.count) {
+            for (uint32_t i = n.first; i < n.first + n.count; i++) {
+                uint32_t p = sc.order[i]; float t;
+                if (tri_test(o, d, sc.tris[p].v0, sc.tris[p].e1, sc.tris[p].e2, tmin, tmax, t)
+                    && (t < h.t || (t == h.t && p < h.prim))) { h.t = t; h.prim = p; }
+            }
+        } else {
+            stack[sp++] = n.right; stack[sp++] = n.left;
+        }
+    }
+}
+
+static inline bool any_brute(const Scene& sc, const f3& o, const f3& d, float tmin, float tmax)
+{
+    for (uint32_t i = 0; i < sc.tris.size(); i++) {
+        float t;
+        if (tri_test(o, d, sc.tris[i].v0, sc.tris[i].e1, sc.tris[i].e2, tmin, tmax, t)) return true;
+    }
+    return false;
+}
+
+static inline bool any_bvh(const Scene& sc, const f3& o, const f3& d, float tmin, float tmax)
+{
+    if (sc.nodes.empty()) return false;
+    f3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    uint32_t stack[128]; int sp = 0; stack[sp++] = 0;
+    while (sp) {
+        const BNode& n = sc.nodes[stack[--sp]];
+        if (!box_test(n, o, inv, tmin, tmax)) continue;
+        if (n.count) {
+            for (uint32_t i = n.first; i < n.first + n.count; i++) {
+                uint32_t p = sc.order[i]; float t;
+                if (tri_test(o, d, sc.tris[p].v0, sc.tris[p].e1, sc.tris[p].e2, tmin, tmax, t)) return true;
+            }
+        } else {
+            stack[sp++] = n.right; stack[sp++] = n.left;
+        }
+    }
+    return false;
+}
+
+/* ------------------------------------------------------------- the launch ---- */
+struct Counters { uint64_t radiance_rays, shadow_rays, paths; };
+
+/* RadiancePayloadRayData, pathTracer.h:19-32 */
+struct PRD {
+    f3 attenuation; uint32_t randomSeed; int depth;
+    f3 emissionColor, radiance, origin, direction; int done;
+};
+
+/* __closesthit__diffuse__ch, pathTracerPrograms.cu:866-1031 */
+static inline void closesthit(const Scene& sc, const pt_params& params, int use_bvh,
+                              const f3& ray_org, const f3& ray_dir, float t_hit, uint32_t prim_idx,
+                              PRD& prd, Counters& cnt)
+{
+    const pt_material& rt = sc.mats[sc.mat_ids[prim_idx]];
+    const Tri& tri = sc.tris[prim_idx];
+    const bool useDirectLighting = params.useDirectLighting != 0;
+    const float roughness = 0.2;                       /* :880 — the material's value is ignored */
+    const float IOR = rt.ior;
+    const int bsdfType = rt.bsdfType;
+    const bool useImportanceSampling = params.useImportanceSampling != 0;
+
+    /* :886-891; v1 - v0 and v2 - v0 are the stored edges (same single subtraction) */
+    const f3 N_0 = normalize(cross(tri.e1, tri.e2));
+    const f3 N = faceforward(N_0, -ray_dir, N_0);
+    const f3 P = ray_org + t_hit * ray_dir;            /* :894 */
+
+    if (prd.depth == 0) prd.emissionColor = mk(rt.emission);   /* :898-901 */
+    else                prd.emissionColor = mk(0.0f);
+
+    uint32_t seed = prd.randomSeed;
+    const f3 Kd = mk(rt.diffuse);
+
+    switch (bsdfType) {
+    case PT_BSDF_DIFFUSE: {                            /* :907-930 */
+        const float z1 = rnd(seed);
+        const float z2 = rnd(seed);
+        OrthonormalBasis onb(N);
+        f3 w_in;
+        if (useImportanceSampling) cosine_sample_hemisphere(z1, z2, w_in);
+        else                       uniform_sample_hemisphere(z1, z2, w_in);
+        onb.inverse_transform(w_in);
+        prd.direction = w_in;
+        prd.origin = P;
+        prd.attenuation *= Kd;
+        break;
+    }
+    case PT_BSDF_METALLIC: {                           /* :931-953 */
+        const float z1 = rnd(seed);
+        const float z2 = rnd(seed);
+        f3 microfacetNormal = sampleGGX(z1, z2, roughness, N);
+        f3 R = reflect(ray_dir, microfacetNormal);
+        prd.direction = R;
+        prd.origin = P + R * 1e-4f;
+        f3 eta = mk((float)1.45, (float)0.7, (float)1.55);
+        f3 k = mk((float)3.0, (float)2.2, (float)3.5);
+        float cosTheta = fmaxf(dot(microfacetNormal, -ray_dir), 0.0f);
+        f3 F = fresnelSchlickConductor(cosTheta, eta, k);
+        f3 color = F * Kd;
+        prd.attenuation *= color;
+        break;
+    }
+    case PT_BSDF_REFRACTION: {                         /* :954-982 */
+        f3 incidentRayDir = normalize(ray_dir);
+        float cos_theta = dot(normalize(-ray_dir), N_0);
+        float F = FrDielectric(cos_theta, 1.0f, IOR);
+        if (rnd(seed) < F) {
+            prd.direction = reflect(incidentRayDir, N_0);
+        } else {
+            f3 refractedDir;
+            bool didRefract = refract(refractedDir, incidentRayDir, N_0, IOR);
+            prd.direction = didRefract ? refractedDir : reflect(incidentRayDir, N_0);
+        }
+        prd.origin = P + prd.direction * 1e-3f;
+        prd.attenuation *= Kd;
+        break;
+    }
+    default: break;
+    }
+
+    const float z1 = rnd(seed);                        /* :985-987, drawn always */
+    const float z2 = rnd(seed);
+    prd.randomSeed = seed;
+
+    if (length(mk(rt.emission)) > 0.0f) { prd.radiance = mk(rt.emission); prd.done = 1; }   /* :992-1000 */
+    else                                { prd.radiance = mk(0.0f); prd.done = 0; }
+
+    if (useDirectLighting && bsdfType != PT_BSDF_REFRACTION) {          /* :1003-1026 */
+        const pt_area_light& light = params.areaLight;
+        const f3 light_pos = mk(light.corner) + mk(light.v1) * z1 + mk(light.v2) * z2;
+        const float Ldist = length(light_pos - P);
+        const f3 L = normalize(light_pos - P);
+        const float nDl = dot(N, L);
+        const float LnDl = -dot(mk(light.normal), L);
+        if (nDl > 0.0f && LnDl > 0.0f) {
+            cnt.shadow_rays++;
+            /* traceOcclusion :651-684: any hit occludes */
+            const bool occluded = use_bvh ? any_bvh(sc, P, L, 0.01f, Ldist - 0.01f)
+                                          : any_brute(sc, P, L, 0.01f, Ldist - 0.01f);
+            if (!occluded) {
+                const float A = length(cross(mk(light.v1), mk(light.v2)));
+                float weight = nDl * LnDl * A / (kPIf * Ldist * Ldist);
+                prd.radiance += mk(light.emission) * weight;
+            }
+        }
+    }
+}
+
+/* __raygen__rg, pathTracerPrograms.cu:707-816, for launch index (x, y) */
+static void raygen_pixel(const Scene& sc, const pt_params& params, int use_bvh, uint32_t x, uint32_t y,
+                         float* accumulation, uint8_t* framebuffer, Counters& cnt)
+{
+    const int w = params.width, h = params.height;
+    const f3 eye = mk(params.cameraEye), U = mk(params.cameraU), V = mk(params.cameraV), W = mk(params.cameraW);
+    const int subframe_index = params.currentFrameIdx;
+    const unsigned maxDepth = params.maxDepth;
+
+    uint32_t seed = tea4(y * w + x, subframe_index);               /* :721 */
+    f3 result = mk(0.0f);
+    int i = params.samplesPerPixel;
+    PRD prd; memset(&prd, 0, sizeof(prd));
+    do {
+        /* :730 make_float2(rnd(seed), rnd(seed)): left-to-right, x first */
+        const float jx = rnd(seed);
+        const float jy = rnd(seed);
+        const float dx = 2.0f * (((float)x + jx) / (float)w) - 1.0f;       /* :732-735 */
+        const float dy = 2.0f * (((float)y + jy) / (float)h) - 1.0f;
+        f3 ray_direction = normalize(dx * U + dy * V + W);
+        f3 ray_origin = eye;
+        prd.attenuation = mk(1.f);
+        prd.randomSeed = seed;
+        prd.depth = 0;
+        cnt.paths++;
+        for (;;) {
+            Hit hit;
+            cnt.radiance_rays++;
+            if (use_bvh) closest_bvh(sc, ray_origin, ray_direction, 0.01f, 1e16f, hit);
+            else         closest_brute(sc, ray_origin, ray_direction, 0.01f, 1e16f, hit);
+            if (hit.prim != 0xFFFFFFFFu) {
+                closesthit(sc, params, use_bvh, ray_origin, ray_direction, hit.t, hit.prim, prd, cnt);
+            } else {                                   /* __miss__ms :833-847, background 0 (PathTracerMain.cpp:568) */
+                prd.radiance = mk(0.0f);
+                prd.emissionColor = mk(0.f);
+                prd.done = 1;
+            }
+            result += prd.emissionColor;               /* :760-761 */
+            result += prd.radiance * prd.attenuation;
+            const float p = dot(prd.attenuation, mk(0.30f, 0.59f, 0.11f));
+            bool russianRoulette = rnd(prd.randomSeed) > p;
+            const bool done = prd.done || russianRoulette || (unsigned)prd.depth >= maxDepth;
+            if (done) break;
+            prd.attenuation = safeDivide(prd.attenuation, p);
+            ray_origin = prd.origin;
+            ray_direction = prd.direction;
+            ++prd.depth;
+        }
+    } while (--i);
+
+    const uint32_t image_index = y * params.width + x;
+    f3 accum_color = result / (float)params.samplesPerPixel;        /* :784 */
+    if (subframe_index > 0) {                                       /* :803-810 */
+        const float a = 1.0f / (float)(subframe_index + 1);
+        const f3 prev = mk(accumulation[4 * image_index], accumulation[4 * image_index + 1], accumulation[4 * image_index + 2]);
+        accum_color = lerp(prev, accum_color, a);
+    }
+    accumulation[4 * image_index + 0] = accum_color.x;
+    accumulation[4 * image_index + 1] = accum_color.y;
+    accumulation[4 * image_index + 2] = accum_color.z;
+    accumulation[4 * image_index + 3] = 1.0f;
+    if (framebuffer) make_color(accum_color, framebuffer + 4 * image_index);
+}
+
+/* sutil/WorkDistribution.h:60-81 */
+static inline void sample_pixel(int num_gpus, int width, int gpu_idx, int sample_idx, int& px, int& py)
+{
+    const int TILE_WIDTH = 8, TILE_HEIGHT = 4;
+    const int tile_strip_width = TILE_WIDTH * num_gpus;
+    const int tile_strip_height = TILE_HEIGHT;
+    const int num_tile_strip_cols = width / tile_strip_width + (width % tile_strip_width == 0 ? 0 : 1);
+    const int tile_strip_idx = sample_idx / (TILE_WIDTH * TILE_HEIGHT);
+    const int tile_strip_y = tile_strip_idx / num_tile_strip_cols;
+    const int tile_strip_x = tile_strip_idx - tile_strip_y * num_tile_strip_cols;
+    const int tile_strip_x_start = tile_strip_x * tile_strip_width;
+    const int tile_strip_y_start = tile_strip_y * tile_strip_height;
+    const int tile_pixel_idx = sample_idx - (tile_strip_idx * TILE_WIDTH * TILE_HEIGHT);
+    const int tile_pixel_y = tile_pixel_idx / TILE_WIDTH;
+    const int tile_pixel_x = tile_pixel_idx - tile_pixel_y * TILE_WIDTH;
+    const int tile_offset_x = (gpu_idx + tile_strip_y % num_gpus) % num_gpus * TILE_WIDTH;
+    py = tile_strip_y_start + tile_pixel_y;
+    px = tile_strip_x_start + tile_pixel_x + tile_offset_x;
+}
+/* sutil/WorkDistribution.h:50-57 */
+static inline int num_samples(int num_gpus, int width, int height)
+{
+    const int tile_strip_width = 8 * num_gpus, tile_strip_height = 4;
+    const int cols = width / tile_strip_width + (width % tile_strip_width == 0 ? 0 : 1);
+    const int rows = height / tile_strip_height + (height % tile_strip_height == 0 ? 0 : 1);
+    return rows * cols * 8 * 4;
+}
+
+} /* namespace */
+
+/* ======================================================================= C API == */
+ORC_API uint32_t orc_tea4(uint32_t v0, uint32_t v1) { return tea4(v0, v1); }
+
+ORC_API void orc_rnd_stream(uint32_t seed, size_t n, uint32_t* states_out, float* values_out)
+{
+    for (size_t i = 0; i < n; i++) { float v = rnd(seed); if (states_out) states_out[i] = seed; if (values_out) values_out[i] = v; }
+}
+
+ORC_API void orc_make_color(const float* rgb, size_t n, uint8_t* rgba_out)
+{
+    for (size_t i = 0; i < n; i++) make_color(mk(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]), rgba_out + 4 * i);
+}
+
+ORC_API void orc_refract(const float* i3, const float* n3, float ior, float* r3, int* ok)
+{
+    f3 r; bool b = refract(r, mk(i3[0], i3[1], i3[2]), mk(n3[0], n3[1], n3[2]), ior);
+    r3[0] = r.x; r3[1] = r.y; r3[2] = r.z; *ok = b;
+}
+
+/* op: 0 normalize(a) 1 reflect(a,b) 2 faceforward(a,b,c) 3 lerp(a,b,s) 4 cross(a,b) 5 a/s */
+ORC_API void orc_vec_op(int op, const float* a, const float* b, const float* c, float s, float* out)
+{
+    f3 A = mk(a[0], a[1], a[2]), B = b ? mk(b[0], b[1], b[2]) : mk(0), C = c ? mk(c[0], c[1], c[2]) : mk(0), r = mk(0);
+    switch (op) {
+    case 0: r = normalize(A); break;
+    case 1: r = reflect(A, B); break;
+    case 2: r = faceforward(A, B, C); break;
+    case 3: r = lerp(A, B, s); break;
+    case 4: r = cross(A, B); break;
+    case 5: r = A / s; break;
+    }
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
+/* Camera::UVWFrame, sutil/Camera.cpp:34-45 */
+ORC_API void orc_camera_uvw(const float* eye, const float* lookat, const float* up, float fovY, float aspect,
+                            float* U3, float* V3, float* W3)
+{
+    f3 W = mk(lookat[0], lookat[1], lookat[2]) - mk(eye[0], eye[1], eye[2]);
+    float wlen = length(W);
+    f3 U = normalize(cross(W, mk(up[0], up[1], up[2])));
+    f3 V = normalize(cross(U, W));
+    float vlen = wlen * tanf(0.5f * fovY * kPIf / 180.0f);
+    V *= vlen;
+    float ulen = vlen * aspect;
+    U *= ulen;
+    U3[0] = U.x; U3[1] = U.y; U3[2] = U.z; V3[0] = V.x; V3[1] = V.y; V3[2] = V.z; W3[0] = W.x; W3[1] = W.y; W3[2] = W.z;
+}
+
+ORC_API int orc_num_samples(int num_gpus, int width, int height) { return num_samples(num_gpus, width, height); }
+ORC_API void orc_sample_pixel(int num_gpus, int width, int gpu_idx, int sample_idx, int* px, int* py)
+{ sample_pixel(num_gpus, width, gpu_idx, sample_idx, *px, *py); }
+
+ORC_API void* orc_scene_create(const float* verts_xyzw, size_t n_verts, const uint32_t* idx, size_t n_tris,
+                               const uint32_t* mat_ids, const pt_material* mats, size_t n_mats)
+{
+    Scene* sc = new Scene();
+    sc->tris.resize(n_tris);
+    for (size_t i = 0; i < n_tris; i++) {
+        uint32_t a = idx[3 * i], b = idx[3 * i + 1], c = idx[3 * i + 2];
+        if (a >= n_verts || b >= n_verts || c >= n_verts) { delete sc; return NULL; }
+        f3 v0 = mk(verts_xyzw[4 * a], verts_xyzw[4 * a + 1], verts_xyzw[4 * a + 2]);
+        f3 v1 = mk(verts_xyzw[4 * b], verts_xyzw[4 * b + 1], verts_xyzw[4 * b + 2]);
+        f3 v2 = mk(verts_xyzw[4 * c], verts_xyzw[4 * c + 1], verts_xyzw[4 * c + 2]);
+        sc->tris[i].v0 = v0; sc->tris[i].e1 = v1 - v0; sc->tris[i].e2 = v2 - v0;
+        if (mat_ids && mat_ids[i] >= n_mats) { delete sc; return NULL; }
+    }
+    if (mat_ids) sc->mat_ids.assign(mat_ids, mat_ids + n_tris);
+    if (mats) sc->mats.assign(mats, mats + n_mats);
+    build_bvh(*sc);
+    return sc;
+}
+ORC_API void orc_scene_destroy(void* s) { delete (Scene*)s; }
+
+ORC_API void orc_trace_closest(void* s, const float* rays, size_t n, int use_bvh, float* t_out, uint32_t* prim_out)
+{
+    const Scene& sc = *(Scene*)s;
+    for (size_t i = 0; i < n; i++) {
+        const float* r = rays + 8 * i; Hit h;
+        if (use_bvh) closest_bvh(sc, mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5]), r[6], r[7], h);
+        else         closest_brute(sc, mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5]), r[6], r[7], h);
+        t_out[i] = h.prim == 0xFFFFFFFFu ? -1.0f : h.t; prim_out[i] = h.prim;
+    }
+}
+ORC_API void orc_trace_any(void* s, const float* rays, size_t n, int use_bvh, uint8_t* hit_out)
+{
+    const Scene& sc = *(Scene*)s;
+    for (size_t i = 0; i < n; i++) {
+        const float* r = rays + 8 * i;
+        hit_out[i] = use_bvh ? any_bvh(sc, mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5]), r[6], r[7])
+                             : any_brute(sc, mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5]), r[6], r[7]);
+    }
+}
+
+/* One launch (LaunchCurrentFrame, PathTracerMain.cpp:184-210) on the host.
+ * accumulation / framebuffer are HOST arrays here (params->accumulationBuffer and
+ * ->frameBuffer are ignored).  rank/world select the WorkDistribution partition.
+ * stats_out: radiance_rays, shadow_rays, paths.  Returns wall seconds. */
+ORC_API double orc_render(void* s, const pt_params* params, float* accumulation, uint8_t* framebuffer,
+                          int use_bvh, int n_threads, int rank, int world, uint64_t* stats_out)
+{
+    const Scene& sc = *(Scene*)s;
+    const int w = params->width, h = params->height;
+    if (world < 1) world = 1;
+    const int total = num_samples(world, w, h);
+    const int chunk = 64;
+    std::atomic<int> next(0);
+    if (n_threads < 1) n_threads = 1;
+    std::vector<Counters> cnts(n_threads);
+    auto t0 = std::chrono::steady_clock::now();
+    auto worker = [&](int tid) {
+        Counters c = {0, 0, 0};
+        for (;;) {
+            int b = next.fetch_add(chunk);
+            if (b >= total) break;
+            int e = std::min(total, b + chunk);
+            for (int si = b; si < e; si++) {
+                int px, py; sample_pixel(world, w, rank, si, px, py);
+                if (px >= w || py >= h) continue;
+                raygen_pixel(sc, *params, use_bvh, (uint32_t)px, (uint32_t)py, accumulation, framebuffer, c);
+            }
+        }
+        cnts[tid] = c;
+    };
+    if (n_threads == 1) worker(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; t++) th.emplace_back(worker, t);
+        for (auto& t : th) t.join();
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    if (stats_out) {
+        stats_out[0] = stats_out[1] = stats_out[2] = 0;
+        for (auto& c : cnts) { stats_out[0] += c.radiance_rays; stats_out[1] += c.shadow_rays; stats_out[2] += c.paths; }
+    }
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
+ORC_API int orc_uses_hw_fma(void)
+{
+#ifdef __FMA__
+    return 1;
+#else
+    return 0;
+#endif
+}
