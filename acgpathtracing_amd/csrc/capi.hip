@@ -1,0 +1,385 @@
+// capi.hip — implementation of include/acgpt.h on the HIP runtime.
+// Each export names the reference function it stands in for (see acgpt.h).  There is no
+// CPU path in this library: every entry point fails if no HIP device is usable.
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/acgpt.h"
+#include "lbvh_build.h"
+#include "pt_device.h"
+#include "render_megakernel.h"
+
+#define PT_API extern "C" __attribute__((visibility("default")))
+
+static_assert(sizeof(pt_params) == 168, "pt_params must mirror PathTraceParams (168 bytes)");
+static_assert(sizeof(pt_material) == 40, "pt_material must mirror Material (40 bytes)");
+static_assert(sizeof(pt_area_light) == 60, "pt_area_light must mirror AreaLight (60 bytes)");
+
+struct pt_ctx {
+    int device = 0;
+    int n_cus = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    ptd::LbvhResult bvh;
+    pt_material* d_mats = nullptr;
+    uint32_t n_mats = 0;
+    uint32_t stack_entries = 8;
+    int blocks_per_cu = 0;        // from the occupancy query for the current stack size
+    int tune_blocks_per_cu = 0;   // user override
+    uint32_t* d_queue = nullptr;              // 8 shard heads
+    unsigned long long* d_counters = nullptr; // 4 counters
+    int rank = 0, world = 1;
+    pt_stats stats;
+    uint64_t scene_serial = 0;
+    std::string err;
+};
+
+static std::mutex g_err_mu;
+static std::string g_err;
+
+static int fail(pt_ctx* c, const std::string& m)
+{
+    if (c) c->err = m;
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    g_err = m;
+    return 1;
+}
+#define CK(c, x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail((c), std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+PT_API uint32_t pt_abi_version(void) { return 1u; }
+
+PT_API const char* pt_last_error(pt_ctx* ctx)
+{
+    if (ctx) return ctx->err.c_str();
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    return g_err.c_str();
+}
+
+PT_API int pt_create(pt_ctx** out, int device_id)
+{
+    if (!out) return fail(nullptr, "pt_create: out is null");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(nullptr, "pt_create: no HIP device (this library has no CPU path)");
+    if (device_id < 0 || device_id >= n) return fail(nullptr, "pt_create: device id out of range");
+    CK(nullptr, hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    CK(nullptr, hipGetDeviceProperties(&prop, device_id));
+    pt_ctx* c = new pt_ctx();
+    c->device = device_id;
+    c->n_cus = prop.multiProcessorCount;
+    memset(&c->stats, 0, sizeof(c->stats));
+    if (hipStreamCreate(&c->own_stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipMalloc((void**)&c->d_queue, 8 * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void**)&c->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess) {
+        delete c;
+        return fail(nullptr, "pt_create: device resource allocation failed");
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return 0;
+}
+
+static void free_scene(pt_ctx* c)
+{
+    ptd::free_lbvh(c->bvh);
+    if (c->d_mats) { (void)hipFree(c->d_mats); c->d_mats = nullptr; }
+    c->n_mats = 0;
+}
+
+PT_API void pt_destroy(pt_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_scene(c);
+    if (c->d_queue) (void)hipFree(c->d_queue);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+PT_API int pt_set_scene(pt_ctx* c, const float* verts_xyzw, size_t n_verts, const uint32_t* idx, size_t n_tris,
+                        const uint32_t* mat_ids, const pt_material* mats, size_t n_mats)
+{
+    if (!c) return fail(nullptr, "pt_set_scene: null context");
+    if (n_tris > 0 && (!verts_xyzw || !idx || !mat_ids || !mats)) return fail(c, "pt_set_scene: null array");
+    if (n_tris >= 0x7FFFFFFEull || n_verts >= 0xFFFFFFFFull) return fail(c, "pt_set_scene: too many triangles or vertices");
+    for (size_t i = 0; i < 3 * n_tris; i++)
+        if (idx[i] >= n_verts) return fail(c, "pt_set_scene: vertex index out of range");
+    for (size_t i = 0; i < n_tris; i++)
+        if (mat_ids[i] >= n_mats) return fail(c, "pt_set_scene: material index out of range (a face without a known usemtl has id 0xFFFFFFFF)");
+    for (size_t i = 0; i < n_mats; i++)
+        if (mats[i].bsdfType < 0 || mats[i].bsdfType > 2) return fail(c, "pt_set_scene: unknown bsdfType");
+    CK(c, hipSetDevice(c->device));
+    CK(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+    std::string err;
+    if (!ptd::build_lbvh(verts_xyzw, n_verts, idx, n_tris, mat_ids, c->stream, c->bvh, err)) return fail(c, "pt_set_scene: " + err);
+    if (n_mats) {
+        CK(c, hipMalloc((void**)&c->d_mats, n_mats * sizeof(pt_material)));
+        CK(c, hipMemcpy(c->d_mats, mats, n_mats * sizeof(pt_material), hipMemcpyHostToDevice));
+    }
+    c->n_mats = (uint32_t)n_mats;
+    // one push per internal node on a root-to-leaf path, at most
+    uint32_t need = c->bvh.max_depth + 1u;
+    if (need < 8u) need = 8u;
+    need = (need + 3u) & ~3u;
+    if (need > 128u) return fail(c, "pt_set_scene: BVH deeper than the traversal stack supports");
+    c->stack_entries = need;
+    CK(c, ptd::render_occupancy(c->stack_entries, &c->blocks_per_cu));
+    if (c->blocks_per_cu < 1) return fail(c, "pt_set_scene: render kernel does not fit on a CU with this stack size");
+    c->scene_serial++;
+    return 0;
+}
+
+PT_API uint64_t pt_scene_handle(pt_ctx* c) { return c ? c->scene_serial : 0; }
+
+PT_API int pt_get_bvh_info(pt_ctx* c, pt_bvh_info* out)
+{
+    if (!c || !out) return fail(c, "pt_get_bvh_info: null argument");
+    memset(out, 0, sizeof(*out));
+    out->n_tris = c->bvh.n_tris;
+    out->n_nodes = c->bvh.n_nodes;
+    out->max_depth = c->bvh.max_depth;
+    out->stack_entries = c->stack_entries;
+    for (int k = 0; k < 3; k++) { out->scene_lo[k] = c->bvh.scene_lo[k]; out->scene_hi[k] = c->bvh.scene_hi[k]; }
+    out->build_ms = c->bvh.build_ms;
+    out->node_bytes = c->bvh.n_nodes * (uint32_t)sizeof(ptd::BvhNode);
+    out->tri_bytes = c->bvh.n_tris * (uint32_t)sizeof(ptd::TriRecord);
+    return 0;
+}
+
+PT_API int pt_set_partition(pt_ctx* c, int rank, int world)
+{
+    if (!c) return fail(nullptr, "pt_set_partition: null context");
+    if (world < 1 || rank < 0 || rank >= world) return fail(c, "pt_set_partition: need 0 <= rank < world");
+    c->rank = rank; c->world = world;
+    return 0;
+}
+
+PT_API int pt_set_tuning(pt_ctx* c, int blocks_per_cu, int)
+{
+    if (!c) return fail(nullptr, "pt_set_tuning: null context");
+    if (blocks_per_cu < 0 || blocks_per_cu > 16) return fail(c, "pt_set_tuning: blocks_per_cu out of range");
+    c->tune_blocks_per_cu = blocks_per_cu;
+    return 0;
+}
+
+PT_API int pt_set_stream(pt_ctx* c, void* s)
+{
+    if (!c) return fail(nullptr, "pt_set_stream: null context");
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return 0;
+}
+
+static ptd::DeviceScene device_scene(pt_ctx* c)
+{
+    ptd::DeviceScene sc;
+    sc.nodes = c->bvh.nodes; sc.tris = c->bvh.tris; sc.mats = c->d_mats;
+    sc.n_tris = c->bvh.n_tris; sc.n_mats = c->n_mats;
+    return sc;
+}
+
+// StaticWorkDistribution::numSamples, sutil/WorkDistribution.h:50-57
+static uint32_t num_samples(int world, uint32_t w, uint32_t h)
+{
+    const uint32_t strip_w = 8u * (uint32_t)world, strip_h = 4u;
+    const uint32_t cols = w / strip_w + (w % strip_w == 0 ? 0 : 1);
+    const uint32_t rows = h / strip_h + (h % strip_h == 0 ? 0 : 1);
+    return rows * cols * 32u;
+}
+
+PT_API int pt_launch(pt_ctx* c, const pt_params* p)
+{
+    if (!c || !p) return fail(c, "pt_launch: null argument");
+    const auto t0 = std::chrono::steady_clock::now();
+    if (p->width == 0 || p->height == 0) return fail(c, "pt_launch: empty image");
+    if ((uint64_t)p->width * p->height > 0x7FFFFFFFull / 8) return fail(c, "pt_launch: image too large");
+    if (p->samplesPerPixel == 0) return fail(c, "pt_launch: samplesPerPixel must be >= 1 (do{}while(--i), pathTracerPrograms.cu:727,780)");
+    if (p->maxDepth < 1 || p->maxDepth > 28) return fail(c, "pt_launch: maxDepth must be in [1, 28] (PathTracerMain.cpp:42, 122-128)");
+    if (!p->accumulationBuffer) return fail(c, "pt_launch: accumulationBuffer is null");
+    if (p->handle != 0 && p->handle != c->scene_serial) return fail(c, "pt_launch: stale scene handle");
+    CK(c, hipSetDevice(c->device));
+
+    ptd::RenderArgs a;
+    memset(&a, 0, sizeof(a));
+    a.scene = device_scene(c);
+    a.accum = (float4*)p->accumulationBuffer;
+    a.fb = (uint32_t*)p->frameBuffer;
+    a.width = p->width; a.height = p->height; a.spp = p->samplesPerPixel; a.maxDepth = p->maxDepth; a.frame = p->currentFrameIdx;
+    a.eye = p->cameraEye; a.U = p->cameraU; a.V = p->cameraV; a.W = p->cameraW;
+    a.light = p->areaLight;
+    a.useDL = p->useDirectLighting ? 1u : 0u;
+    a.useIS = p->useImportanceSampling ? 1u : 0u;
+    a.rank = c->rank; a.world = c->world;
+    a.total_samples = num_samples(c->world, p->width, p->height);
+    a.shard_size = ((a.total_samples + 7u) / 8u + 63u) & ~63u;
+    a.queue_heads = c->d_queue;
+    a.counters = c->d_counters;
+    a.stack_entries = c->stack_entries;
+
+    int bpc = c->tune_blocks_per_cu > 0 ? c->tune_blocks_per_cu : c->blocks_per_cu;
+    if (bpc < 1) {   // no scene yet: empty world, every ray misses
+        CK(c, ptd::render_occupancy(c->stack_entries, &c->blocks_per_cu));
+        bpc = c->blocks_per_cu > 0 ? c->blocks_per_cu : 1;
+    }
+    if (bpc > c->blocks_per_cu && c->blocks_per_cu > 0) bpc = c->blocks_per_cu;
+    uint32_t grid = (uint32_t)c->n_cus * (uint32_t)bpc;
+    const uint32_t waves_needed = (a.total_samples + 63u) / 64u;
+    const uint32_t blocks_needed = (waves_needed + (ptd::kRenderThreads / 64) - 1) / (ptd::kRenderThreads / 64);
+    if (grid > blocks_needed) grid = blocks_needed;
+    if (grid < 1) grid = 1;
+
+    CK(c, hipMemsetAsync(c->d_queue, 0, 8 * sizeof(uint32_t), c->stream));
+    CK(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), c->stream));
+    CK(c, hipEventRecord(c->ev0, c->stream));
+    CK(c, ptd::launch_render(a, grid, c->stream));
+    CK(c, hipEventRecord(c->ev1, c->stream));
+    unsigned long long h[4];
+    CK(c, hipMemcpyAsync(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipStreamSynchronize(c->stream));            // CUDA_SYNC_CHECK, PathTracerMain.cpp:209
+    float ms = 0.0f;
+    CK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->stats.radiance_rays = h[0];
+    c->stats.shadow_rays = h[1];
+    c->stats.paths = h[2];
+    c->stats.pixels = (uint32_t)h[3];
+    c->stats.kernel_ms = ms;
+    c->stats.launch_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+}
+
+PT_API int pt_resolve_framebuffer(pt_ctx* c, const float* accum, uint8_t* fb, size_t n_pixels)
+{
+    if (!c || !accum || !fb) return fail(c, "pt_resolve_framebuffer: null argument");
+    if (n_pixels > 0x7FFFFFFFull) return fail(c, "pt_resolve_framebuffer: too many pixels");
+    CK(c, hipSetDevice(c->device));
+    if (n_pixels) CK(c, ptd::launch_resolve((const float4*)accum, (uint32_t*)fb, (uint32_t)n_pixels, c->stream));
+    CK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+PT_API int pt_get_stats(pt_ctx* c, pt_stats* out)
+{
+    if (!c || !out) return fail(c, "pt_get_stats: null argument");
+    *out = c->stats;
+    return 0;
+}
+
+template <typename F>
+static int trace_common(pt_ctx* c, const float* rays, size_t n, size_t out_bytes_a, void* out_a, size_t out_bytes_b, void* out_b, F launch)
+{
+    if (n == 0) return 0;
+    if (n > 0x7FFFFFFFull) return fail(c, "pt_trace: too many rays");
+    CK(c, hipSetDevice(c->device));
+    float* d_rays = nullptr; void* d_a = nullptr; void* d_b = nullptr;
+    int rc = 0;
+    hipError_t e = hipMalloc((void**)&d_rays, n * 32);
+    if (e == hipSuccess) e = hipMalloc(&d_a, out_bytes_a);
+    if (e == hipSuccess && out_bytes_b) e = hipMalloc(&d_b, out_bytes_b);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rays, rays, n * 32, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch(d_rays, d_a, d_b);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_a, d_a, out_bytes_a, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && out_bytes_b) e = hipMemcpyAsync(out_b, d_b, out_bytes_b, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = fail(c, std::string("pt_trace: ") + hipGetErrorString(e));
+    if (d_rays) (void)hipFree(d_rays);
+    if (d_a) (void)hipFree(d_a);
+    if (d_b) (void)hipFree(d_b);
+    return rc;
+}
+
+PT_API int pt_trace_closest(pt_ctx* c, const float* rays, size_t n, float* t_out, uint32_t* prim_out)
+{
+    if (!c || (n && (!rays || !t_out || !prim_out))) return fail(c, "pt_trace_closest: null argument");
+    const ptd::DeviceScene sc = device_scene(c);
+    const uint32_t se = c->stack_entries;
+    hipStream_t s = c->stream;
+    return trace_common(c, rays, n, n * 4, t_out, n * 4, prim_out, [&](float* d_rays, void* a, void* b) {
+        return ptd::launch_trace_closest(sc, se, d_rays, (uint32_t)n, (float*)a, (uint32_t*)b, s);
+    });
+}
+
+PT_API int pt_trace_any(pt_ctx* c, const float* rays, size_t n, uint8_t* hit_out)
+{
+    if (!c || (n && (!rays || !hit_out))) return fail(c, "pt_trace_any: null argument");
+    const ptd::DeviceScene sc = device_scene(c);
+    const uint32_t se = c->stack_entries;
+    hipStream_t s = c->stream;
+    return trace_common(c, rays, n, n, hit_out, 0, nullptr, [&](float* d_rays, void* a, void*) {
+        return ptd::launch_trace_any(sc, se, d_rays, (uint32_t)n, (uint8_t*)a, s);
+    });
+}
+
+PT_API int pt_read_morton(pt_ctx* c, uint32_t* codes_sorted, uint32_t* prims_sorted)
+{
+    if (!c || !codes_sorted || !prims_sorted) return fail(c, "pt_read_morton: null argument");
+    if (c->bvh.n_tris == 0) return 0;
+    CK(c, hipSetDevice(c->device));
+    CK(c, hipMemcpy(codes_sorted, c->bvh.keys_sorted, (size_t)c->bvh.n_tris * 4, hipMemcpyDeviceToHost));
+    CK(c, hipMemcpy(prims_sorted, c->bvh.vals_sorted, (size_t)c->bvh.n_tris * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+PT_API int pt_device_malloc(pt_ctx* c, void** out, size_t bytes)
+{
+    if (!c || !out) return fail(c, "pt_device_malloc: null argument");
+    CK(c, hipSetDevice(c->device));
+    CK(c, hipMalloc(out, bytes ? bytes : 4));
+    return 0;
+}
+PT_API int pt_device_free(pt_ctx* c, void* ptr)
+{
+    if (!c) return fail(nullptr, "pt_device_free: null context");
+    CK(c, hipSetDevice(c->device));
+    CK(c, hipFree(ptr));
+    return 0;
+}
+PT_API int pt_device_memset(pt_ctx* c, void* ptr, int value, size_t bytes)
+{
+    if (!c) return fail(nullptr, "pt_device_memset: null context");
+    CK(c, hipSetDevice(c->device));
+    CK(c, hipMemsetAsync(ptr, value, bytes, c->stream));
+    CK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+PT_API int pt_copy_to_host(pt_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!c) return fail(nullptr, "pt_copy_to_host: null context");
+    CK(c, hipSetDevice(c->device));
+    CK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+PT_API int pt_copy_to_device(pt_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!c) return fail(nullptr, "pt_copy_to_device: null context");
+    CK(c, hipSetDevice(c->device));
+    CK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    CK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+PT_API int pt_host_malloc_mapped(pt_ctx* c, void** host_out, void** device_out, size_t bytes)
+{
+    if (!c || !host_out || !device_out) return fail(c, "pt_host_malloc_mapped: null argument");
+    CK(c, hipSetDevice(c->device));
+    CK(c, hipHostMalloc(host_out, bytes ? bytes : 4, hipHostMallocMapped | hipHostMallocPortable));
+    CK(c, hipHostGetDevicePointer(device_out, *host_out, 0));
+    return 0;
+}
+PT_API int pt_host_free_mapped(pt_ctx* c, void* host_ptr)
+{
+    if (!c) return fail(nullptr, "pt_host_free_mapped: null context");
+    CK(c, hipHostFree(host_ptr));
+    return 0;
+}

@@ -1,0 +1,27 @@
+// lbvh_build.h — host entry of the on-device LBVH build (see lbvh_build.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <cstring>
+#include "pt_device.h"
+
+namespace ptd {
+
+struct LbvhResult {
+    BvhNode*   nodes = nullptr;        // device, n_nodes
+    TriRecord* tris = nullptr;         // device, n_tris, Morton order
+    uint32_t*  keys_sorted = nullptr;  // device, n_tris
+    uint32_t*  vals_sorted = nullptr;  // device, n_tris (original triangle index per slot)
+    uint32_t   n_tris = 0, n_nodes = 0, max_depth = 0;
+    float      scene_lo[3] = {0, 0, 0}, scene_hi[3] = {0, 0, 0};
+    float      build_ms = 0.0f;
+};
+
+// Host arrays in, device BVH out.  Synchronous on return.  false + err on failure.
+bool build_lbvh(const float* h_verts_xyzw, size_t n_verts, const uint32_t* h_idx, size_t n_tris,
+                const uint32_t* h_mat_ids, hipStream_t stream, LbvhResult& out, std::string& err);
+
+void free_lbvh(LbvhResult& r);
+
+}  // namespace ptd

@@ -1,0 +1,408 @@
+// lbvh_build.hip — on-device LBVH construction for gfx950.
+//
+// Replaces optixAccelBuild + compaction (PathTracerMain.cpp:329-397); the reference holds
+// no BVH code of its own (its comment at :300-302), so the structure is ours:
+//   1. k_prepare    per triangle: edges, padded AABB, scene bounds (ordered-uint atomics)
+//   2. k_morton     30-bit Morton code of the AABB centre inside the scene bounds
+//   3. radix sort   LSD, 4 passes x 8 bits, stable (ties keep triangle order):
+//                   k_hist -> k_scan -> k_scatter, ranks by wave64 ballot match
+//   4. k_hierarchy  Karras 2012 radix tree over the sorted codes (ties broken by index)
+//   5. k_refit      bottom-up: the second thread to reach a node writes its 64-byte
+//                   traversal node (both child boxes) and height; agent-scope acq_rel
+//                   counters carry the child boxes between CUs
+// Everything is deterministic: the sorted order and therefore the tree are unique for a
+// given triangle list.
+#include "pt_device.h"
+#include "lbvh_build.h"
+#include <vector>
+
+namespace ptd {
+
+__device__ __forceinline__ uint32_t f2ord(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float ord2f(uint32_t u)
+{
+    uint32_t b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+#ifdef __HIP_DEVICE_COMPILE__
+    return __uint_as_float(b);
+#else
+    float f; memcpy(&f, &b, 4); return f;
+#endif
+}
+
+// --- 1. triangle records + bounds -------------------------------------------------
+__global__ void k_prepare(const float4* __restrict__ verts, const uint32_t* __restrict__ idx,
+                          const uint32_t* __restrict__ mat_ids, uint32_t n_tris,
+                          TriRecord* __restrict__ tri_unsorted, float4* __restrict__ tri_lo, float4* __restrict__ tri_hi,
+                          uint32_t* __restrict__ scene_bounds /*6 ordered uints: lo xyz, hi xyz*/)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (i < n_tris) {
+        const float4 a = verts[idx[3 * i]], b = verts[idx[3 * i + 1]], c = verts[idx[3 * i + 2]];
+        TriRecord r;
+        r.r0 = make_float4(a.x, a.y, a.z, b.x - a.x);
+        r.r1 = make_float4(b.y - a.y, b.z - a.z, c.x - a.x, c.y - a.y);
+        r.r2 = make_float4(c.z - a.z, __uint_as_float(i), __uint_as_float(mat_ids[i]), 0.0f);
+        tri_unsorted[i] = r;
+        const float pa[3] = {a.x, a.y, a.z}, pb[3] = {b.x, b.y, b.z}, pc[3] = {c.x, c.y, c.z};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float l = fminf(pa[k], fminf(pb[k], pc[k])), h = fmaxf(pa[k], fmaxf(pb[k], pc[k]));
+            // pad: the triangle test accepts rays a few ulps outside the exact triangle
+            float pad = 1e-5f * fmaxf(1.0f, fmaxf(fabsf(l), fabsf(h)));
+            lo[k] = l - pad; hi[k] = h + pad;
+        }
+        tri_lo[i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+        tri_hi[i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    }
+    // wave reduction, then one atomic per wave and component
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float l = lo[k], h = hi[k];
+        for (int off = 32; off > 0; off >>= 1) {
+            l = fminf(l, __shfl_xor(l, off));
+            h = fmaxf(h, __shfl_xor(h, off));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (l <= h) {
+                atomicMin(&scene_bounds[k], f2ord(l));
+                atomicMax(&scene_bounds[3 + k], f2ord(h));
+            }
+        }
+    }
+}
+
+// --- 2. Morton codes -----------------------------------------------------------------
+__device__ __forceinline__ uint32_t expand10(uint32_t v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__global__ void k_morton(const float4* __restrict__ tri_lo, const float4* __restrict__ tri_hi, uint32_t n_tris,
+                         const uint32_t* __restrict__ scene_bounds, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tris) return;
+    const float slo[3] = {ord2f(scene_bounds[0]), ord2f(scene_bounds[1]), ord2f(scene_bounds[2])};
+    const float shi[3] = {ord2f(scene_bounds[3]), ord2f(scene_bounds[4]), ord2f(scene_bounds[5])};
+    const float4 l = tri_lo[i], h = tri_hi[i];
+    const float c[3] = {0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z)};
+    uint32_t q[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float ext = shi[k] - slo[k];
+        float u = ext > 0.0f ? (c[k] - slo[k]) / ext : 0.0f;
+        u = fminf(fmaxf(u * 1024.0f, 0.0f), 1023.0f);
+        q[k] = (uint32_t)u;
+    }
+    keys[i] = (expand10(q[0]) << 2) | (expand10(q[1]) << 1) | expand10(q[2]);
+    vals[i] = i;
+}
+
+// --- 3. LSD radix sort, 8 bits per pass ---------------------------------------------
+constexpr int kSortThreads = 256;
+constexpr int kSortItems = 8;
+constexpr int kSortTile = kSortThreads * kSortItems;
+
+__global__ void __launch_bounds__(kSortThreads)
+k_hist(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t n_blocks, uint32_t* __restrict__ block_hist)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kSortTile;
+#pragma unroll
+    for (int r = 0; r < kSortItems; r++) {
+        const uint32_t i = base + r * kSortThreads + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    block_hist[threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// exclusive scan of `count` values in place, one workgroup of 1024 threads
+__global__ void __launch_bounds__(1024) k_scan(uint32_t* __restrict__ data, uint32_t count)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (count + 1023u) / 1024u;
+    const uint32_t b = threadIdx.x * per, e = min(count, b + per);
+    uint32_t s = 0;
+    for (uint32_t i = b; i < e; i++) s += data[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;
+    for (uint32_t i = b; i < e; i++) { uint32_t v = data[i]; data[i] = run; run += v; }
+}
+
+__global__ void __launch_bounds__(kSortThreads)
+k_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t n, int shift,
+          uint32_t n_blocks, const uint32_t* __restrict__ block_offs,
+          uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out)
+{
+    __shared__ uint32_t running[256];          // keys of this digit already placed by this block
+    __shared__ uint32_t wave_cnt[4][256];      // per-round, per-wave digit counts
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    running[tid] = block_offs[tid * n_blocks + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < 4; w++) wave_cnt[w][tid] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kSortTile;
+    for (int r = 0; r < kSortItems; r++) {
+        const uint32_t i = base + r * kSortThreads + tid;
+        const bool valid = i < n;
+        uint32_t key = 0, val = 0, digit = 0;
+        if (valid) { key = keys_in[i]; val = vals_in[i]; digit = (key >> shift) & 255u; }
+        // lanes of this wave holding the same digit (ballot match over the 8 digit bits)
+        unsigned long long same = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const unsigned long long bal = __ballot((digit >> b) & 1u);
+            same &= ((digit >> b) & 1u) ? bal : ~bal;
+        }
+        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        const uint32_t rank = __popcll(same & below);
+        if (valid && rank == 0) wave_cnt[wave][digit] = __popcll(same);
+        __syncthreads();
+        if (valid) {
+            uint32_t off = running[digit] + rank;
+            for (uint32_t w = 0; w < wave; w++) off += wave_cnt[w][digit];
+            keys_out[off] = key;
+            vals_out[off] = val;
+        }
+        __syncthreads();
+        {
+            uint32_t s = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) { s += wave_cnt[w][tid]; wave_cnt[w][tid] = 0; }
+            running[tid] += s;
+        }
+        __syncthreads();
+    }
+}
+
+// --- 4. Karras radix tree -----------------------------------------------------------
+__device__ __forceinline__ int delta(const uint32_t* __restrict__ keys, int n, int i, int j)
+{
+    if (j < 0 || j >= n) return -1;
+    const uint32_t a = keys[i], b = keys[j];
+    if (a == b) return 32 + __clz((uint32_t)i ^ (uint32_t)j);
+    return __clz(a ^ b);
+}
+// children: >= 0 internal node, < 0 leaf (~sorted slot).  parent arrays for the refit.
+__global__ void k_hierarchy(const uint32_t* __restrict__ keys, int n, int2* __restrict__ children,
+                            int* __restrict__ node_parent, int* __restrict__ leaf_parent)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = delta(keys, n, i, j);
+    int s = 0;
+    int t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + min(d, 0);
+    const int lo = min(i, j), hi = max(i, j);
+    int left, right;
+    if (lo == gamma) { left = ~gamma; leaf_parent[gamma] = i; } else { left = gamma; node_parent[gamma] = i; }
+    if (hi == gamma + 1) { right = ~(gamma + 1); leaf_parent[gamma + 1] = i; } else { right = gamma + 1; node_parent[gamma + 1] = i; }
+    children[i] = make_int2(left, right);
+    if (i == 0) node_parent[0] = -1;
+}
+
+// --- 5. sorted leaves + bottom-up refit ------------------------------------------------
+__global__ void k_gather_leaves(const uint32_t* __restrict__ vals_sorted, uint32_t n, const TriRecord* __restrict__ tri_unsorted,
+                                TriRecord* __restrict__ tris)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) tris[i] = tri_unsorted[vals_sorted[i]];
+}
+
+__global__ void k_refit(int n, const uint32_t* __restrict__ vals_sorted, const float4* __restrict__ tri_lo, const float4* __restrict__ tri_hi,
+                        const int2* __restrict__ children, const int* __restrict__ node_parent, const int* __restrict__ leaf_parent,
+                        uint32_t* __restrict__ visit, float4* __restrict__ node_lo, float4* __restrict__ node_hi /* .w = height */,
+                        BvhNode* __restrict__ nodes)
+{
+    const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (leaf >= n) return;
+    int cur = leaf_parent[leaf];
+    while (cur >= 0) {
+        // release our subtree's boxes, acquire the sibling's: the second arrival proceeds
+        const uint32_t prev = __hip_atomic_fetch_add(&visit[cur], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == 0) return;
+        const int2 ch = children[cur];
+        float4 l0, h0, l1, h1; float hgt0, hgt1;
+        if (ch.x < 0) { const uint32_t p = vals_sorted[~ch.x]; l0 = tri_lo[p]; h0 = tri_hi[p]; hgt0 = 0.0f; }
+        else { l0 = node_lo[ch.x]; h0 = node_hi[ch.x]; hgt0 = h0.w; }
+        if (ch.y < 0) { const uint32_t p = vals_sorted[~ch.y]; l1 = tri_lo[p]; h1 = tri_hi[p]; hgt1 = 0.0f; }
+        else { l1 = node_lo[ch.y]; h1 = node_hi[ch.y]; hgt1 = h1.w; }
+        BvhNode nd;
+        nd.a = make_float4(l0.x, l0.y, l0.z, h0.x);
+        nd.b = make_float4(h0.y, h0.z, l1.x, l1.y);
+        nd.c = make_float4(l1.z, h1.x, h1.y, h1.z);
+        nd.d = make_int4(ch.x, ch.y, 0, 0);
+        nodes[cur] = nd;
+        node_lo[cur] = make_float4(fminf(l0.x, l1.x), fminf(l0.y, l1.y), fminf(l0.z, l1.z), 0.0f);
+        node_hi[cur] = make_float4(fmaxf(h0.x, h1.x), fmaxf(h0.y, h1.y), fmaxf(h0.z, h1.z), 1.0f + fmaxf(hgt0, hgt1));
+        cur = node_parent[cur];
+    }
+}
+
+// Single-triangle scene: one node whose second child is an empty box.
+__global__ void k_single_node(const float4* __restrict__ tri_lo, const float4* __restrict__ tri_hi, BvhNode* __restrict__ nodes,
+                              float4* __restrict__ node_hi)
+{
+    const float4 l = tri_lo[0], h = tri_hi[0];
+    BvhNode nd;
+    nd.a = make_float4(l.x, l.y, l.z, h.x);
+    nd.b = make_float4(h.y, h.z, INFINITY, INFINITY);
+    nd.c = make_float4(INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    nd.d = make_int4(~0, ~0, 0, 0);
+    nodes[0] = nd;
+    node_hi[0] = make_float4(h.x, h.y, h.z, 1.0f);
+}
+
+#define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); return false; } } while (0)
+
+namespace {
+// scratch allocations of one build, released on every exit path
+struct Scratch {
+    std::vector<void*> ptrs;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    template <typename T> hipError_t alloc(T** p, size_t bytes)
+    {
+        hipError_t e = hipMalloc((void**)p, bytes ? bytes : 4);
+        if (e == hipSuccess) ptrs.push_back((void*)*p);
+        return e;
+    }
+    ~Scratch()
+    {
+        for (void* p : ptrs) (void)hipFree(p);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+    }
+};
+}  // namespace
+
+void free_lbvh(LbvhResult& r)
+{
+    if (r.nodes) (void)hipFree(r.nodes);
+    if (r.tris) (void)hipFree(r.tris);
+    if (r.keys_sorted) (void)hipFree(r.keys_sorted);
+    if (r.vals_sorted) (void)hipFree(r.vals_sorted);
+    r = LbvhResult();
+}
+
+static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t* h_idx, uint32_t n,
+                       const uint32_t* h_mat_ids, hipStream_t stream, LbvhResult& out, std::string& err)
+{
+    Scratch sc;
+    float4* d_verts; uint32_t* d_idx; uint32_t* d_mat;
+    TriRecord* d_unsorted; float4 *d_tlo, *d_thi, *d_nlo, *d_nhi;
+    uint32_t *d_bounds, *d_keys[2], *d_vals[2], *d_hist, *d_visit;
+    int2* d_children; int *d_nparent, *d_lparent;
+    const uint32_t n_nodes = n > 1 ? n - 1 : 1;
+    const uint32_t blocks = (n + 255) / 256;
+    const uint32_t sort_blocks = (n + kSortTile - 1) / kSortTile;
+    const uint32_t init_bounds[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    uint32_t h_bounds[6];
+    float4 root_hi;
+    int cur = 0;
+
+    HIPCK(sc.alloc(&d_verts, n_verts * 16));
+    HIPCK(sc.alloc(&d_idx, (size_t)n * 12));
+    HIPCK(sc.alloc(&d_mat, (size_t)n * 4));
+    HIPCK(sc.alloc(&d_unsorted, (size_t)n * sizeof(TriRecord)));
+    HIPCK(sc.alloc(&d_tlo, (size_t)n * 16));
+    HIPCK(sc.alloc(&d_thi, (size_t)n * 16));
+    HIPCK(sc.alloc(&d_nlo, (size_t)n_nodes * 16));
+    HIPCK(sc.alloc(&d_nhi, (size_t)n_nodes * 16));
+    HIPCK(sc.alloc(&d_bounds, 24));
+    for (int k = 0; k < 2; k++) { HIPCK(sc.alloc(&d_keys[k], (size_t)n * 4)); HIPCK(sc.alloc(&d_vals[k], (size_t)n * 4)); }
+    HIPCK(sc.alloc(&d_hist, (size_t)256 * sort_blocks * 4));
+    HIPCK(sc.alloc(&d_visit, (size_t)n_nodes * 4));
+    HIPCK(sc.alloc(&d_children, (size_t)n_nodes * 8));
+    HIPCK(sc.alloc(&d_nparent, (size_t)n_nodes * 4));
+    HIPCK(sc.alloc(&d_lparent, (size_t)n * 4));
+    HIPCK(hipMalloc((void**)&out.nodes, (size_t)n_nodes * sizeof(BvhNode)));
+    HIPCK(hipMalloc((void**)&out.tris, (size_t)n * sizeof(TriRecord)));
+    HIPCK(hipMalloc((void**)&out.keys_sorted, (size_t)n * 4));
+    HIPCK(hipMalloc((void**)&out.vals_sorted, (size_t)n * 4));
+
+    HIPCK(hipMemcpyAsync(d_verts, h_verts_xyzw, n_verts * 16, hipMemcpyHostToDevice, stream));
+    HIPCK(hipMemcpyAsync(d_idx, h_idx, (size_t)n * 12, hipMemcpyHostToDevice, stream));
+    HIPCK(hipMemcpyAsync(d_mat, h_mat_ids, (size_t)n * 4, hipMemcpyHostToDevice, stream));
+    HIPCK(hipMemcpyAsync(d_bounds, init_bounds, 24, hipMemcpyHostToDevice, stream));
+    HIPCK(hipMemsetAsync(d_visit, 0, (size_t)n_nodes * 4, stream));
+    HIPCK(hipEventCreate(&sc.ev0));
+    HIPCK(hipEventCreate(&sc.ev1));
+    HIPCK(hipEventRecord(sc.ev0, stream));
+
+    k_prepare<<<blocks, 256, 0, stream>>>(d_verts, d_idx, d_mat, n, d_unsorted, d_tlo, d_thi, d_bounds);
+    k_morton<<<blocks, 256, 0, stream>>>(d_tlo, d_thi, n, d_bounds, d_keys[0], d_vals[0]);
+    for (int pass = 0; pass < 4; pass++) {
+        const int shift = 8 * pass;
+        k_hist<<<sort_blocks, kSortThreads, 0, stream>>>(d_keys[cur], n, shift, sort_blocks, d_hist);
+        k_scan<<<1, 1024, 0, stream>>>(d_hist, 256u * sort_blocks);
+        k_scatter<<<sort_blocks, kSortThreads, 0, stream>>>(d_keys[cur], d_vals[cur], n, shift, sort_blocks, d_hist,
+                                                             d_keys[cur ^ 1], d_vals[cur ^ 1]);
+        cur ^= 1;
+    }
+    HIPCK(hipMemcpyAsync(out.keys_sorted, d_keys[cur], (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+    HIPCK(hipMemcpyAsync(out.vals_sorted, d_vals[cur], (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+    k_gather_leaves<<<blocks, 256, 0, stream>>>(d_vals[cur], n, d_unsorted, out.tris);
+    if (n > 1) {
+        k_hierarchy<<<(n - 1 + 255) / 256, 256, 0, stream>>>(d_keys[cur], (int)n, d_children, d_nparent, d_lparent);
+        k_refit<<<blocks, 256, 0, stream>>>((int)n, d_vals[cur], d_tlo, d_thi, d_children, d_nparent, d_lparent, d_visit,
+                                            d_nlo, d_nhi, out.nodes);
+    } else {
+        k_single_node<<<1, 1, 0, stream>>>(d_tlo, d_thi, out.nodes, d_nhi);
+    }
+    HIPCK(hipGetLastError());
+    HIPCK(hipEventRecord(sc.ev1, stream));
+    HIPCK(hipMemcpyAsync(h_bounds, d_bounds, 24, hipMemcpyDeviceToHost, stream));
+    HIPCK(hipMemcpyAsync(&root_hi, d_nhi, 16, hipMemcpyDeviceToHost, stream));
+    HIPCK(hipStreamSynchronize(stream));
+    HIPCK(hipEventElapsedTime(&out.build_ms, sc.ev0, sc.ev1));
+    for (int k = 0; k < 3; k++) { out.scene_lo[k] = ord2f(h_bounds[k]); out.scene_hi[k] = ord2f(h_bounds[3 + k]); }
+    out.n_nodes = n_nodes;
+    out.max_depth = (uint32_t)root_hi.w;
+    return true;
+}
+
+bool build_lbvh(const float* h_verts_xyzw, size_t n_verts, const uint32_t* h_idx, size_t n_tris,
+                const uint32_t* h_mat_ids, hipStream_t stream, LbvhResult& out, std::string& err)
+{
+    out = LbvhResult();
+    out.n_tris = (uint32_t)n_tris;
+    if (n_tris == 0) return true;
+    if (!build_impl(h_verts_xyzw, n_verts, h_idx, (uint32_t)n_tris, h_mat_ids, stream, out, err)) {
+        (void)hipStreamSynchronize(stream);
+        free_lbvh(out);
+        return false;
+    }
+    return true;
+}
+
+}  // namespace ptd

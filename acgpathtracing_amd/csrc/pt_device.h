@@ -1,0 +1,195 @@
+// pt_device.h — device-side data layout and the per-lane building blocks of the gfx950
+// path-trace kernels: float3 algebra, PRNG, ray/triangle test, LDS-stack BVH traversal.
+//
+// HBM layout (all arrays owned by the context, built once per scene):
+//   nodes  : BvhNode[n_nodes], 64 B each, two child boxes + two child references.
+//            child >= 0 : internal node index;  child < 0 : leaf, ~child = slot in `tris`.
+//   tris   : TriRecord[n_tris], 48 B each, in Morton order: v0, e1 = v1-v0, e2 = v2-v0,
+//            original triangle index, material id.  Edges are the single fp32 subtraction
+//            the reference's closest-hit performs (pathTracerPrograms.cu:890), so shading
+//            needs no second fetch through the index buffer.
+//   mats   : pt_material[n_mats] (40 B, HitGroupData's payload, pathTracer.h:118-127).
+// Compile with -ffp-contract=off: the only fused multiply-adds are the explicit ones in
+// tri_test(), which must match oracle/oracle_pt.cpp bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/acgpt.h"
+
+namespace ptd {
+
+struct __attribute__((aligned(16))) BvhNode {
+    float4 a;   // lo0.x lo0.y lo0.z hi0.x
+    float4 b;   // hi0.y hi0.z lo1.x lo1.y
+    float4 c;   // lo1.z hi1.x hi1.y hi1.z
+    int4   d;   // child0 child1 - -
+};
+static_assert(sizeof(BvhNode) == 64, "node size");
+
+struct __attribute__((aligned(16))) TriRecord {
+    float4 r0;  // v0.x v0.y v0.z e1.x
+    float4 r1;  // e1.y e1.z e2.x e2.y
+    float4 r2;  // e2.z prim(bits) mat(bits) -
+};
+static_assert(sizeof(TriRecord) == 48, "tri size");
+
+struct DeviceScene {
+    const BvhNode*     nodes;
+    const TriRecord*   tris;
+    const pt_material* mats;
+    uint32_t n_tris;
+    uint32_t n_mats;
+};
+
+constexpr int   kSentinel  = 0x7FFFFFFF;   // stack bottom marker (never a valid node index)
+constexpr float kFarWiden  = 1.0000004f;   // conservative slab test (Ize 2013)
+constexpr float kPIf       = 3.14159265358979323846f;
+
+// ------------------------------------------------------------------ float3 ----
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 mk(float x, float y, float z) { f3 r = {x, y, z}; return r; }
+__device__ __forceinline__ f3 mk(float s) { return mk(s, s, s); }
+__device__ __forceinline__ f3 mk(const pt_float3& p) { return mk(p.x, p.y, p.z); }
+__device__ __forceinline__ f3 operator-(const f3& a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ f3 operator+(const f3& a, const f3& b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(const f3& a, const f3& b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator*(const f3& a, const f3& b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 operator*(const f3& a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 operator*(float s, const f3& a) { return mk(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ f3 operator/(const f3& a, const f3& b) { return mk(a.x / b.x, a.y / b.y, a.z / b.z); }
+__device__ __forceinline__ f3 operator/(const f3& a, float s) { float inv = 1.0f / s; return a * inv; }
+__device__ __forceinline__ void operator+=(f3& a, const f3& b) { a.x += b.x; a.y += b.y; a.z += b.z; }
+__device__ __forceinline__ void operator*=(f3& a, const f3& b) { a.x *= b.x; a.y *= b.y; a.z *= b.z; }
+__device__ __forceinline__ float dot(const f3& a, const f3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross(const f3& a, const f3& b)
+{ return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ float length(const f3& v) { return sqrtf(dot(v, v)); }
+__device__ __forceinline__ f3 normalize(const f3& v) { float invLen = 1.0f / sqrtf(dot(v, v)); return v * invLen; }
+__device__ __forceinline__ f3 reflect(const f3& i, const f3& n) { return i - 2.0f * n * dot(n, i); }
+__device__ __forceinline__ f3 faceforward(const f3& n, const f3& i, const f3& nref) { return n * copysignf(1.0f, dot(i, nref)); }
+__device__ __forceinline__ f3 lerp3(const f3& a, const f3& b, float t) { return a + t * (b - a); }
+__device__ __forceinline__ float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }
+
+// -------------------------------------------------------------------- PRNG ----
+// tea<4>, cuda/random.h:31-46
+__device__ __forceinline__ uint32_t tea4(uint32_t val0, uint32_t val1)
+{
+    uint32_t v0 = val0, v1 = val1, s0 = 0;
+#pragma unroll
+    for (uint32_t n = 0; n < 4; n++) {
+        s0 += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    return v0;
+}
+// lcg + rnd, cuda/random.h:49-55, 64-67
+__device__ __forceinline__ float rnd(uint32_t& prev)
+{
+    prev = 1664525u * prev + 1013904223u;
+    return (float)(prev & 0x00FFFFFFu) / (float)0x01000000;
+}
+
+// ------------------------------------------------------ ray / triangle test ----
+__device__ __forceinline__ float dot_fma(const f3& a, const f3& b)
+{ return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ f3 cross_fma(const f3& a, const f3& b)
+{
+    return mk(__builtin_fmaf(a.y, b.z, -(a.z * b.y)),
+              __builtin_fmaf(a.z, b.x, -(a.x * b.z)),
+              __builtin_fmaf(a.x, b.y, -(a.y * b.x)));
+}
+// Moeller-Trumbore, two-sided, open interval (tmin, tmax); same operations in the same
+// order as tri_test() in oracle/oracle_pt.cpp.
+__device__ __forceinline__ bool tri_test(const f3& o, const f3& d, const f3& v0, const f3& e1, const f3& e2,
+                                         float tmin, float tmax, float& t_out)
+{
+    f3 p = cross_fma(d, e2);
+    float det = dot_fma(e1, p);
+    f3 s = o - v0;
+    float U = dot_fma(s, p);
+    f3 q = cross_fma(s, e1);
+    float V = dot_fma(d, q);
+    float T = dot_fma(e2, q);
+    if (det < 0.0f) { det = -det; U = -U; V = -V; T = -T; }
+    bool ok = (det > 0.0f) && !(U < 0.0f || V < 0.0f || U + V > det);
+    float t = T / det;
+    ok = ok && (t > tmin && t < tmax);
+    t_out = t;
+    return ok;
+}
+
+// ------------------------------------------------------------ LDS lane stack ----
+// One stack per lane, entry-major / lane-minor so a wave-wide push or pop touches 64
+// consecutive dwords (conflict-free ds_read_b32 / ds_write_b32).
+struct LaneStack {
+    uint32_t* base;   // &lds[wave_region + lane]
+    __device__ __forceinline__ void push(int sp, int v) const { base[sp * 64] = (uint32_t)v; }
+    __device__ __forceinline__ int pop(int sp) const { return (int)base[sp * 64]; }
+};
+
+struct HitRec { float t; int slot; uint32_t prim; };
+
+// One ray per lane through the two-child BVH.  ANY_HIT: return at the first triangle hit
+// (traceOcclusion, pathTracerPrograms.cu:651-684).  Otherwise closest hit, equal t -> lowest
+// original triangle index.  `active` lanes only; inactive lanes fall straight through.
+template <bool ANY_HIT>
+__device__ __forceinline__ bool traverse(const DeviceScene& sc, const LaneStack& st, bool active,
+                                         const f3& o, const f3& d, float tmin, float tmax, HitRec& hit)
+{
+    hit.t = tmax; hit.slot = -1; hit.prim = 0xFFFFFFFFu;
+    if (sc.n_tris == 0) return false;
+    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    int sp = 0;
+    int node = active ? 0 : kSentinel;
+    bool found = false;
+    while (node != kSentinel) {
+        if (node >= 0) {
+            const BvhNode* np = sc.nodes + node;
+            const float4 a = np->a, b = np->b, c = np->c;
+            const int4 ch = np->d;
+            // child 0: lo (a.x a.y a.z) hi (a.w b.x b.y); child 1: lo (b.z b.w c.x) hi (c.y c.z c.w)
+            float x0 = (a.x - o.x) * ix, x1 = (a.w - o.x) * ix;
+            float y0 = (a.y - o.y) * iy, y1 = (b.x - o.y) * iy;
+            float z0 = (a.z - o.z) * iz, z1 = (b.y - o.z) * iz;
+            float n0 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
+            float f0 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1)) * kFarWiden;
+            f0 = fminf(f0, hit.t);
+            float u0 = (b.z - o.x) * ix, u1 = (c.y - o.x) * ix;
+            float v0 = (b.w - o.y) * iy, v1 = (c.z - o.y) * iy;
+            float w0 = (c.x - o.z) * iz, w1 = (c.w - o.z) * iz;
+            float n1 = fmaxf(fmaxf(fminf(u0, u1), fminf(v0, v1)), fmaxf(fminf(w0, w1), tmin));
+            float f1 = fminf(fminf(fmaxf(u0, u1), fmaxf(v0, v1)), fmaxf(w0, w1)) * kFarWiden;
+            f1 = fminf(f1, hit.t);
+            const bool h0 = n0 <= f0, h1 = n1 <= f1;
+            if (h0 && h1) {
+                const bool first0 = n0 <= n1;
+                st.push(sp, first0 ? ch.y : ch.x);
+                sp++;
+                node = first0 ? ch.x : ch.y;
+            } else if (h0) {
+                node = ch.x;
+            } else if (h1) {
+                node = ch.y;
+            } else {
+                if (sp == 0) node = kSentinel; else { sp--; node = st.pop(sp); }
+            }
+        } else {
+            const int slot = ~node;
+            const TriRecord* tp = sc.tris + slot;
+            const float4 r0 = tp->r0, r1 = tp->r1, r2 = tp->r2;
+            float t;
+            const bool ok = tri_test(o, d, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), tmin, tmax, t);
+            if (ANY_HIT) {
+                if (ok) { found = true; node = kSentinel; continue; }
+            } else {
+                const uint32_t prim = __float_as_uint(r2.y);
+                if (ok && (t < hit.t || (t == hit.t && prim < hit.prim))) { hit.t = t; hit.slot = slot; hit.prim = prim; found = true; }
+            }
+            if (sp == 0) node = kSentinel; else { sp--; node = st.pop(sp); }
+        }
+    }
+    return found;
+}
+
+}  // namespace ptd

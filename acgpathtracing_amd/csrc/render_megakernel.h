@@ -1,0 +1,34 @@
+// render_megakernel.h — launch interface of the persistent path-trace kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "pt_device.h"
+
+namespace ptd {
+
+constexpr int kRenderThreads = 256;   // 4 waves per workgroup
+
+struct RenderArgs {
+    DeviceScene scene;
+    float4*   accum;        // PathTraceParams::accumulationBuffer
+    uint32_t* fb;           // PathTraceParams::frameBuffer (uchar4 packed), may be null
+    uint32_t  width, height, spp, maxDepth, frame;
+    pt_float3 eye, U, V, W;
+    pt_area_light light;
+    uint32_t  useDL, useIS;
+    int       rank, world;
+    uint32_t  total_samples;   // StaticWorkDistribution::numSamples for `world`
+    uint32_t  shard_size;      // queue shard length (8 shards)
+    uint32_t* queue_heads;     // 8 counters, zeroed before the launch
+    unsigned long long* counters;   // radiance rays, shadow rays, paths, pixels
+    uint32_t  stack_entries;
+};
+
+hipError_t render_occupancy(uint32_t stack_entries, int* blocks_per_cu);
+hipError_t launch_render(const RenderArgs& args, uint32_t grid_blocks, hipStream_t stream);
+hipError_t launch_resolve(const float4* accum, uint32_t* fb, uint32_t n, hipStream_t stream);
+hipError_t launch_trace_closest(const DeviceScene& sc, uint32_t stack_entries, const float* d_rays, uint32_t n,
+                                float* d_t, uint32_t* d_prim, hipStream_t stream);
+hipError_t launch_trace_any(const DeviceScene& sc, uint32_t stack_entries, const float* d_rays, uint32_t n,
+                            uint8_t* d_hit, hipStream_t stream);
+
+}  // namespace ptd

@@ -1,0 +1,62 @@
+"""Multi-GPU plumbing: one process per GPU, pixel tiles per rank, one exchange at the end.
+
+The path shards by pixels (pathTracerPrograms.cu:782-814 writes only its own image_index), so the
+data path needs no collective while rendering.  Each rank renders the 8x4 tiles that
+sutil/WorkDistribution.h:60-81 assigns to it into a ZERO-INITIALISED full-size float4 buffer; one
+`reduce(SUM)` to rank 0 (RCCL over xGMI with backend "nccl", gloo on CPU in the tests) then yields
+exactly the single-GPU image: every pixel receives one non-zero term, and x + 0 + ... + 0 is exact.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_process_group(backend=None):
+    """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
+    rank, world, local_rank = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, world, local_rank
+
+
+def reduce_accumulation(accum, dst=0):
+    """Sum the per-rank accumulation buffers onto `dst`.  `accum` is a float32 tensor [H, W, 4]
+    (CUDA for RCCL, CPU for gloo) that is zero outside this rank's tiles.  In place on dst."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
+    return accum
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value, device=None):
+    """MAX of a python float over all ranks (the bench contract's timing rule)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(values, device=None):
+    """SUM of a list of python numbers over all ranks."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.tolist()]

@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py — Mray/s and ms/frame of the path-trace hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one launch of the hot path at the reference's launch granularity
+(LaunchCurrentFrame, PathTracerMain.cpp:184-210): 128 samples per pixel over the whole
+1920x1080 image, frame index advancing, progressive accumulation.  8 steps are one 1024-spp
+output frame = BASELINE.json configs[1] (Cornell-box OBJ, 1080p, 1024 spp, 8 bounces, importance
+sampling + direct lighting).  The scene and BVH are resident in HBM before the timed region.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank renders its own 8x4 pixel
+tiles (sutil/WorkDistribution.h) of the same steps, then ONE RCCL reduce of the float4
+accumulation buffer to rank 0 + make_color there, all inside the timed region.  Per-GPU work
+shrinks with N -> "scaling": "strong".
+
+One JSON line on rank 0.  `roofline` prices the megakernel against HBM (SURVEY.md §8d:
+B_ray = 64*ceil(log2 T) + 64 bytes per ray + 36*W*H per launch); `cpu_baseline` times the CPU
+oracle (oracle/, scalar C++ restatement, std::thread over the host cores) on a bounded sample of
+the same workload — reported, not the target.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+WIDTH, HEIGHT = 1920, 1080
+SPP_PER_LAUNCH = 128
+MAX_DEPTH = 8
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="cornell_box_diffuse.obj")
+    ap.add_argument("--width", type=int, default=WIDTH)
+    ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--spp", type=int, default=SPP_PER_LAUNCH)
+    ap.add_argument("--max-depth", type=int, default=MAX_DEPTH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-spp", type=int, default=4)
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--save", default="", help="write the final framebuffer as PPM (rank 0)")
+    return ap.parse_args()
+
+
+def cpu_baseline(pt, obj, params, cpu_spp):
+    """The oracle timed on the host cores (bounded sample: same image size, depth and toggles,
+    cpu_spp samples, one frame).  Only this function touches oracle/."""
+    import oracle_lib
+    from scene_utils import copy_params
+    orc = oracle_lib.load()
+    sc = orc.scene(obj.getVerticesFloat(), obj.getIndexBuffer(), obj.getMaterialIndices(), obj.getMaterials())
+    q = copy_params(params)
+    q.samplesPerPixel = cpu_spp
+    q.currentFrameIdx = 0
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    _, _, st, secs = sc.render(q, use_bvh=True, threads=cores)
+    rays = st["radiance_rays"] + st["shadow_rays"]
+    sc.close()
+    return {"value": rays / secs / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+            "sample": "%s %dx%d maxDepth %d IS+DL, %d spp x 1 frame (%.1f s, %d rays)" %
+                      (os.path.basename(obj.path), q.width, q.height, q.maxDepth, cpu_spp, secs, rays)}, rays / max(1, q.width * q.height * cpu_spp)
+
+
+def main():
+    a = parse()
+    import torch
+    import acgpathtracing_amd as pt
+    from acgpathtracing_amd import _native, distributed as D
+    from scene_utils import make_params
+
+    rank, world, local_rank = D.env_rank_world()
+    if a.gpus != world and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    D.init_process_group("nccl" if world > 1 else None)
+    L = _native.hip()
+
+    # ---- scene + context (outside the timed region: inputs resident in HBM) ------------------
+    obj = pt.TinyObjWrapper(os.path.join(pt.SCENES, a.scene))
+    obj.path = a.scene
+    if not obj.dataLoaded:
+        raise SystemExit("cannot load scene %s" % a.scene)
+    state = pt.PathTracerState()
+    pt.createDeviceContext(state, local_rank)
+    pt.buildTheAccelarationStructure(state, obj)
+    p = make_params(a.width, a.height, a.spp, a.max_depth, True, True)
+    p.handle = state.params.handle
+    accum = torch.zeros((a.height, a.width, 4), dtype=torch.float32, device=dev)
+    fb = torch.zeros((a.height, a.width, 4), dtype=torch.uint8, device=dev)
+    p.accumulationBuffer = accum.data_ptr()
+    p.frameBuffer = fb.data_ptr() if world == 1 else None
+    state.params = p
+    assert L.pt_set_partition(state.context, rank, world) == 0
+    assert L.pt_set_stream(state.context, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    if a.blocks_per_cu:
+        assert L.pt_set_tuning(state.context, a.blocks_per_cu, 0) == 0
+    info = pt.getBvhInfo(state)
+
+    def step(frame):
+        state.params.currentFrameIdx = frame
+        rc = L.pt_launch(state.context, C.byref(state.params))
+        if rc != 0:
+            raise SystemExit("pt_launch failed: %s" % L.pt_last_error(state.context).decode())
+        return pt.getStats(state)
+
+    for w in range(a.warmup):
+        step(w)
+    accum.zero_()
+
+    # ---- timed region ---------------------------------------------------------------------------
+    D.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rays = shadow = paths = 0
+    kernel_ms = []
+    for k in range(a.steps):
+        s = step(k)
+        rays += int(s.radiance_rays); shadow += int(s.shadow_rays); paths += int(s.paths)
+        kernel_ms.append(float(s.kernel_ms))
+    if world > 1:
+        D.reduce_accumulation(accum, dst=0)
+        if rank == 0:
+            assert L.pt_resolve_framebuffer(state.context, C.c_void_p(accum.data_ptr()), C.c_void_p(fb.data_ptr()), a.width * a.height) == 0
+    torch.cuda.synchronize(); D.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = D.max_over_ranks(elapsed, dev if world > 1 else None)
+    tot_rays, tot_shadow, tot_paths = D.sum_over_ranks([rays, shadow, paths], dev if world > 1 else None)
+
+    # ---- report ---------------------------------------------------------------------------------------
+    if rank == 0:
+        all_rays = tot_rays + tot_shadow
+        T = max(2, info.n_tris)
+        b_ray = 64 * math.ceil(math.log2(T)) + 64
+        f_ray = 48 * math.ceil(math.log2(T)) + 168
+        k_avg_ms = sum(kernel_ms) / max(1, len(kernel_ms))
+        my_rays_per_launch = (rays + shadow) / max(1, a.steps)
+        my_pixels = a.width * a.height / world
+        algo_bytes = my_rays_per_launch * b_ray + 36.0 * my_pixels
+        achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(prof):
+            try:
+                traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mray/s at 1080p, 1024 spp, 8 bounces (radiance + shadow rays per second)",
+            "value": all_rays / elapsed / 1e6,
+            "unit": "Mray/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed * 1e3 / a.steps,
+            "ms_per_frame_1024spp": elapsed * 1e3 / a.steps * (1024.0 / a.spp),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "%s (%d triangles), %dx%d, %d spp per launch x %d launches, maxDepth %d, importance sampling + direct lighting"
+                                   % (a.scene, info.n_tris, a.width, a.height, a.spp, a.steps, a.max_depth),
+                       "parallelism": "pixel tiles 8x4 over %d GPU(s)%s" % (world, ", RCCL reduce of float4 accumulation" if world > 1 else ""),
+                       "rays": int(all_rays), "paths": int(tot_paths), "rays_per_path": all_rays / max(1.0, tot_paths),
+                       "bvh": {"nodes": info.n_nodes, "max_depth": info.max_depth, "stack_entries": info.stack_entries, "build_ms": info.build_ms}},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "k_render", "kernel_ms_avg": k_avg_ms,
+                         "algorithmic_bytes_per_ray": b_ray, "algorithmic_bytes_per_launch": algo_bytes,
+                         "valu_frac_secondary": (my_rays_per_launch * f_ray / (k_avg_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS) if k_avg_ms > 0 else 0.0},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            base, _ = cpu_baseline(pt, obj, p, a.cpu_spp)
+            out["cpu_baseline"] = base
+        if a.save:
+            img = fb.cpu().numpy()[::-1, :, :3]
+            with open(a.save, "wb") as fh:
+                fh.write(b"P6\n%d %d\n255\n" % (a.width, a.height))
+                fh.write(np.ascontiguousarray(img).tobytes())
+        print(json.dumps(out), flush=True)
+    D.barrier()
+    pt_ctx = state.context
+    state.params.accumulationBuffer = None
+    L.pt_destroy(pt_ctx)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -151,6 +151,11 @@ int pt_launch(pt_ctx* ctx, const pt_params* params);
  * untouched.  world == 1 (the default) renders everything.                   */
 int pt_set_partition(pt_ctx* ctx, int rank, int world);
 
+/* After a multi-GPU reduce the root holds the summed accumulation but no colours: this applies
+ * make_color (cuda/helpers.h:58-63, as pathTracerPrograms.cu:814 does per pixel) to n_pixels of
+ * a float4 DEVICE array and writes uchar4 into frameBuffer (device or mapped host).          */
+int pt_resolve_framebuffer(pt_ctx* ctx, const float* accumulation_rgba, uint8_t* framebuffer_rgba, size_t n_pixels);
+
 /* Launch geometry override (0 = automatic): persistent workgroups per CU. */
 int pt_set_tuning(pt_ctx* ctx, int blocks_per_cu, int reserved);
 

@@ -1,0 +1,44 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Make sure the host library and the oracle exist (cheap no-op when up to date)."""
+    from acgpathtracing_amd import _build
+    _build.build_host()
+    _build.build_oracle()
+    return True
+
+
+@pytest.fixture(scope="session")
+def oracle(built):
+    import oracle_lib
+    return oracle_lib.load()
+
+
+@pytest.fixture(scope="session")
+def gpu_state_factory():
+    """Creates PathTracerState objects on cuda:0 through the C ABI and cleans them up."""
+    import acgpathtracing_amd as pt
+    made = []
+
+    def make(obj_path, **kw):
+        state, obj = pt.setup(obj_path, **kw)
+        made.append(state)
+        return state, obj
+
+    yield make
+    for s in made:
+        pt.CleanAllTheThings(s)
