@@ -32,8 +32,9 @@ struct pt_ctx {
     uint32_t stack_entries = 8;
     int blocks_per_cu = 0;        // from the occupancy query for the current stack size
     int tune_blocks_per_cu = 0;   // user override
+    int variant = ptd::kDefaultVariant;   // render kernel variant (render_megakernel.hip)
     uint32_t* d_queue = nullptr;              // 8 shard heads
-    unsigned long long* d_counters = nullptr; // 4 counters
+    unsigned long long* d_counters = nullptr; // 8 counters
     int rank = 0, world = 1;
     pt_stats stats;
     uint64_t scene_serial = 0;
@@ -78,7 +79,7 @@ PT_API int pt_create(pt_ctx** out, int device_id)
     memset(&c->stats, 0, sizeof(c->stats));
     if (hipStreamCreate(&c->own_stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipMalloc((void**)&c->d_queue, 8 * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void**)&c->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc((void**)&c->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess) {
         delete c;
         return fail(nullptr, "pt_create: device resource allocation failed");
     }
@@ -136,7 +137,7 @@ PT_API int pt_set_scene(pt_ctx* c, const float* verts_xyzw, size_t n_verts, cons
     need = (need + 3u) & ~3u;
     if (need > 128u) return fail(c, "pt_set_scene: BVH deeper than the traversal stack supports");
     c->stack_entries = need;
-    CK(c, ptd::render_occupancy(c->stack_entries, &c->blocks_per_cu));
+    CK(c, ptd::render_occupancy(c->variant, c->stack_entries, c->bvh.n_nodes, &c->blocks_per_cu));
     if (c->blocks_per_cu < 1) return fail(c, "pt_set_scene: render kernel does not fit on a CU with this stack size");
     c->scene_serial++;
     return 0;
@@ -167,11 +168,16 @@ PT_API int pt_set_partition(pt_ctx* c, int rank, int world)
     return 0;
 }
 
-PT_API int pt_set_tuning(pt_ctx* c, int blocks_per_cu, int)
+PT_API int pt_set_tuning(pt_ctx* c, int blocks_per_cu, int variant)
 {
     if (!c) return fail(nullptr, "pt_set_tuning: null context");
     if (blocks_per_cu < 0 || blocks_per_cu > 16) return fail(c, "pt_set_tuning: blocks_per_cu out of range");
+    if (variant < 0 || variant >= ptd::render_variant_count()) return fail(c, "pt_set_tuning: unknown kernel variant");
+    CK(c, hipSetDevice(c->device));
     c->tune_blocks_per_cu = blocks_per_cu;
+    c->variant = variant;
+    CK(c, ptd::render_occupancy(c->variant, c->stack_entries, c->bvh.n_nodes, &c->blocks_per_cu));
+    if (c->blocks_per_cu < 1) return fail(c, "pt_set_tuning: this kernel variant does not fit the current scene in LDS");
     return 0;
 }
 
@@ -185,7 +191,7 @@ PT_API int pt_set_stream(pt_ctx* c, void* s)
 static ptd::DeviceScene device_scene(pt_ctx* c)
 {
     ptd::DeviceScene sc;
-    sc.nodes = c->bvh.nodes; sc.tris = c->bvh.tris; sc.mats = c->d_mats;
+    sc.nodes = c->bvh.nodes; sc.qnodes = c->bvh.qnodes; sc.grid = c->bvh.grid; sc.tris = c->bvh.tris; sc.mats = c->d_mats;
     sc.n_tris = c->bvh.n_tris; sc.n_mats = c->n_mats;
     return sc;
 }
@@ -227,25 +233,27 @@ PT_API int pt_launch(pt_ctx* c, const pt_params* p)
     a.queue_heads = c->d_queue;
     a.counters = c->d_counters;
     a.stack_entries = c->stack_entries;
+    a.n_lds_nodes = c->bvh.n_nodes;
 
     int bpc = c->tune_blocks_per_cu > 0 ? c->tune_blocks_per_cu : c->blocks_per_cu;
     if (bpc < 1) {   // no scene yet: empty world, every ray misses
-        CK(c, ptd::render_occupancy(c->stack_entries, &c->blocks_per_cu));
+        CK(c, ptd::render_occupancy(c->variant, c->stack_entries, c->bvh.n_nodes, &c->blocks_per_cu));
         bpc = c->blocks_per_cu > 0 ? c->blocks_per_cu : 1;
     }
     if (bpc > c->blocks_per_cu && c->blocks_per_cu > 0) bpc = c->blocks_per_cu;
     uint32_t grid = (uint32_t)c->n_cus * (uint32_t)bpc;
     const uint32_t waves_needed = (a.total_samples + 63u) / 64u;
-    const uint32_t blocks_needed = (waves_needed + (ptd::kRenderThreads / 64) - 1) / (ptd::kRenderThreads / 64);
+    const uint32_t wpb = (uint32_t)ptd::render_variant_threads(c->variant) / 64u;
+    const uint32_t blocks_needed = (waves_needed + wpb - 1) / wpb;
     if (grid > blocks_needed) grid = blocks_needed;
     if (grid < 1) grid = 1;
 
     CK(c, hipMemsetAsync(c->d_queue, 0, 8 * sizeof(uint32_t), c->stream));
-    CK(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(unsigned long long), c->stream));
+    CK(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
     CK(c, hipEventRecord(c->ev0, c->stream));
-    CK(c, ptd::launch_render(a, grid, c->stream));
+    CK(c, ptd::launch_render(c->variant, a, grid, c->stream));
     CK(c, hipEventRecord(c->ev1, c->stream));
-    unsigned long long h[4];
+    unsigned long long h[8];
     CK(c, hipMemcpyAsync(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     CK(c, hipStreamSynchronize(c->stream));            // CUDA_SYNC_CHECK, PathTracerMain.cpp:209
     float ms = 0.0f;
@@ -254,6 +262,11 @@ PT_API int pt_launch(pt_ctx* c, const pt_params* p)
     c->stats.shadow_rays = h[1];
     c->stats.paths = h[2];
     c->stats.pixels = (uint32_t)h[3];
+    c->stats.trav_wave_steps = h[4];
+    c->stats.trav_lane_steps = h[5];
+    c->stats.shade_wave_rounds = h[6];
+    c->stats.shade_lane_rounds = h[7];
+    c->stats.grid_blocks = grid;
     c->stats.kernel_ms = ms;
     c->stats.launch_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return 0;

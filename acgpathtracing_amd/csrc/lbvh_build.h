@@ -9,7 +9,9 @@
 namespace ptd {
 
 struct LbvhResult {
-    BvhNode*   nodes = nullptr;        // device, n_nodes
+    BvhNode*   nodes = nullptr;        // device, n_nodes (fp32 boxes, 64 B)
+    QNode*     qnodes = nullptr;       // device, n_nodes (16-bit grid boxes, 32 B)
+    QGrid      grid = {};              // world -> grid transform of qnodes
     TriRecord* tris = nullptr;         // device, n_tris, Morton order
     uint32_t*  keys_sorted = nullptr;  // device, n_tris
     uint32_t*  vals_sorted = nullptr;  // device, n_tris (original triangle index per slot)

@@ -231,6 +231,52 @@ __global__ void k_hierarchy(const uint32_t* __restrict__ keys, int n, int2* __re
     if (i == 0) node_parent[0] = -1;
 }
 
+// --- quantisation grid: 16 bits per axis over the (slightly enlarged) scene box -------------------
+__host__ __device__ inline QGrid make_qgrid_f(const float lo[3], const float hi[3])
+{
+    QGrid g;
+    float c[3], o[3];
+    for (int k = 0; k < 3; k++) {
+        const float ext = hi[k] - lo[k];
+        c[k] = (ext * 1.0001f + 1e-30f) / 65531.0f;     // all boxes land in cells [2, 65533]
+        o[k] = lo[k] - 2.0f * c[k];
+    }
+    g.ox = o[0]; g.oy = o[1]; g.oz = o[2];
+    g.cx = c[0]; g.cy = c[1]; g.cz = c[2];
+    g.icx = 1.0f / c[0]; g.icy = 1.0f / c[1]; g.icz = 1.0f / c[2];
+    return g;
+}
+__device__ __forceinline__ QGrid make_qgrid(const uint32_t* __restrict__ scene_bounds)
+{
+    const float lo[3] = {ord2f(scene_bounds[0]), ord2f(scene_bounds[1]), ord2f(scene_bounds[2])};
+    const float hi[3] = {ord2f(scene_bounds[3]), ord2f(scene_bounds[4]), ord2f(scene_bounds[5])};
+    return make_qgrid_f(lo, hi);
+}
+// outward rounding plus one cell of slack on each side: the slack absorbs the rounding of the
+// ray's own world->grid transform (a few 1e-3 cells), see DESIGN.md
+__device__ __forceinline__ uint32_t q_lo(float w, float o, float ic)
+{
+    const float g = floorf((w - o) * ic) - 1.0f;
+    return (uint32_t)fminf(fmaxf(g, 0.0f), 65535.0f);
+}
+__device__ __forceinline__ uint32_t q_hi(float w, float o, float ic)
+{
+    const float g = ceilf((w - o) * ic) + 1.0f;
+    return (uint32_t)fminf(fmaxf(g, 0.0f), 65535.0f);
+}
+__device__ __forceinline__ QNode quantise_node(const QGrid g, const float4 l0, const float4 h0, const float4 l1, const float4 h1, int c0, int c1)
+{
+    QNode q;
+    // an empty box (lo = +inf, hi = -inf) quantises to lo = 65535, hi = 0: never hit
+    q.a = make_uint4(q_lo(l0.x, g.ox, g.icx) | (q_lo(l0.y, g.oy, g.icy) << 16),
+                     q_lo(l0.z, g.oz, g.icz) | (q_hi(h0.x, g.ox, g.icx) << 16),
+                     q_hi(h0.y, g.oy, g.icy) | (q_hi(h0.z, g.oz, g.icz) << 16), (uint32_t)c0);
+    q.b = make_uint4(q_lo(l1.x, g.ox, g.icx) | (q_lo(l1.y, g.oy, g.icy) << 16),
+                     q_lo(l1.z, g.oz, g.icz) | (q_hi(h1.x, g.ox, g.icx) << 16),
+                     q_hi(h1.y, g.oy, g.icy) | (q_hi(h1.z, g.oz, g.icz) << 16), (uint32_t)c1);
+    return q;
+}
+
 // --- 5. sorted leaves + bottom-up refit ------------------------------------------------
 __global__ void k_gather_leaves(const uint32_t* __restrict__ vals_sorted, uint32_t n, const TriRecord* __restrict__ tri_unsorted,
                                 TriRecord* __restrict__ tris)
@@ -242,7 +288,7 @@ __global__ void k_gather_leaves(const uint32_t* __restrict__ vals_sorted, uint32
 __global__ void k_refit(int n, const uint32_t* __restrict__ vals_sorted, const float4* __restrict__ tri_lo, const float4* __restrict__ tri_hi,
                         const int2* __restrict__ children, const int* __restrict__ node_parent, const int* __restrict__ leaf_parent,
                         uint32_t* __restrict__ visit, float4* __restrict__ node_lo, float4* __restrict__ node_hi /* .w = height */,
-                        BvhNode* __restrict__ nodes)
+                        BvhNode* __restrict__ nodes, QNode* __restrict__ qnodes, const uint32_t* __restrict__ scene_bounds)
 {
     const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
     if (leaf >= n) return;
@@ -263,6 +309,7 @@ __global__ void k_refit(int n, const uint32_t* __restrict__ vals_sorted, const f
         nd.c = make_float4(l1.z, h1.x, h1.y, h1.z);
         nd.d = make_int4(ch.x, ch.y, 0, 0);
         nodes[cur] = nd;
+        qnodes[cur] = quantise_node(make_qgrid(scene_bounds), l0, h0, l1, h1, ch.x, ch.y);
         node_lo[cur] = make_float4(fminf(l0.x, l1.x), fminf(l0.y, l1.y), fminf(l0.z, l1.z), 0.0f);
         node_hi[cur] = make_float4(fmaxf(h0.x, h1.x), fmaxf(h0.y, h1.y), fmaxf(h0.z, h1.z), 1.0f + fmaxf(hgt0, hgt1));
         cur = node_parent[cur];
@@ -271,7 +318,7 @@ __global__ void k_refit(int n, const uint32_t* __restrict__ vals_sorted, const f
 
 // Single-triangle scene: one node whose second child is an empty box.
 __global__ void k_single_node(const float4* __restrict__ tri_lo, const float4* __restrict__ tri_hi, BvhNode* __restrict__ nodes,
-                              float4* __restrict__ node_hi)
+                              float4* __restrict__ node_hi, QNode* __restrict__ qnodes, const uint32_t* __restrict__ scene_bounds)
 {
     const float4 l = tri_lo[0], h = tri_hi[0];
     BvhNode nd;
@@ -280,6 +327,8 @@ __global__ void k_single_node(const float4* __restrict__ tri_lo, const float4* _
     nd.c = make_float4(INFINITY, -INFINITY, -INFINITY, -INFINITY);
     nd.d = make_int4(~0, ~0, 0, 0);
     nodes[0] = nd;
+    qnodes[0] = quantise_node(make_qgrid(scene_bounds), l, h, make_float4(INFINITY, INFINITY, INFINITY, 0.0f),
+                              make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f), ~0, ~0);
     node_hi[0] = make_float4(h.x, h.y, h.z, 1.0f);
 }
 
@@ -308,6 +357,7 @@ struct Scratch {
 void free_lbvh(LbvhResult& r)
 {
     if (r.nodes) (void)hipFree(r.nodes);
+    if (r.qnodes) (void)hipFree(r.qnodes);
     if (r.tris) (void)hipFree(r.tris);
     if (r.keys_sorted) (void)hipFree(r.keys_sorted);
     if (r.vals_sorted) (void)hipFree(r.vals_sorted);
@@ -346,6 +396,7 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
     HIPCK(sc.alloc(&d_nparent, (size_t)n_nodes * 4));
     HIPCK(sc.alloc(&d_lparent, (size_t)n * 4));
     HIPCK(hipMalloc((void**)&out.nodes, (size_t)n_nodes * sizeof(BvhNode)));
+    HIPCK(hipMalloc((void**)&out.qnodes, (size_t)n_nodes * sizeof(QNode)));
     HIPCK(hipMalloc((void**)&out.tris, (size_t)n * sizeof(TriRecord)));
     HIPCK(hipMalloc((void**)&out.keys_sorted, (size_t)n * 4));
     HIPCK(hipMalloc((void**)&out.vals_sorted, (size_t)n * 4));
@@ -375,9 +426,9 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
     if (n > 1) {
         k_hierarchy<<<(n - 1 + 255) / 256, 256, 0, stream>>>(d_keys[cur], (int)n, d_children, d_nparent, d_lparent);
         k_refit<<<blocks, 256, 0, stream>>>((int)n, d_vals[cur], d_tlo, d_thi, d_children, d_nparent, d_lparent, d_visit,
-                                            d_nlo, d_nhi, out.nodes);
+                                            d_nlo, d_nhi, out.nodes, out.qnodes, d_bounds);
     } else {
-        k_single_node<<<1, 1, 0, stream>>>(d_tlo, d_thi, out.nodes, d_nhi);
+        k_single_node<<<1, 1, 0, stream>>>(d_tlo, d_thi, out.nodes, d_nhi, out.qnodes, d_bounds);
     }
     HIPCK(hipGetLastError());
     HIPCK(hipEventRecord(sc.ev1, stream));
@@ -388,6 +439,7 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
     for (int k = 0; k < 3; k++) { out.scene_lo[k] = ord2f(h_bounds[k]); out.scene_hi[k] = ord2f(h_bounds[3 + k]); }
     out.n_nodes = n_nodes;
     out.max_depth = (uint32_t)root_hi.w;
+    out.grid = make_qgrid_f(out.scene_lo, out.scene_hi);
     return true;
 }
 

@@ -33,8 +33,28 @@ struct __attribute__((aligned(16))) TriRecord {
 };
 static_assert(sizeof(TriRecord) == 48, "tri size");
 
+// Quantised node, 32 B = two 16-byte loads: each child box as six 16-bit grid coordinates
+// (rounded outward by one cell, so the box test stays conservative) + the child reference.
+//   a = { lo0.x | lo0.y<<16, lo0.z | hi0.x<<16, hi0.y | hi0.z<<16, child0 }
+//   b = { lo1.x | lo1.y<<16, lo1.z | hi1.x<<16, hi1.y | hi1.z<<16, child1 }
+// Rays are moved into grid space once (QGrid), so decoding is an integer->float convert.
+struct __attribute__((aligned(16))) QNode {
+    uint4 a;
+    uint4 b;
+};
+static_assert(sizeof(QNode) == 32, "qnode size");
+
+// world -> grid: g = (w - origin) * inv_cell ; cell sizes per axis
+struct QGrid {
+    float ox, oy, oz;
+    float icx, icy, icz;
+    float cx, cy, cz;
+};
+
 struct DeviceScene {
     const BvhNode*     nodes;
+    const QNode*       qnodes;
+    QGrid              grid;
     const TriRecord*   tris;
     const pt_material* mats;
     uint32_t n_tris;
@@ -42,7 +62,7 @@ struct DeviceScene {
 };
 
 constexpr int   kSentinel  = 0x7FFFFFFF;   // stack bottom marker (never a valid node index)
-constexpr float kFarWiden  = 1.0000004f;   // conservative slab test (Ize 2013)
+constexpr float kFarWiden  = 1.000001f;    // conservative slab test (Ize 2013) incl. the 1-ulp v_rcp_f32 direction
 constexpr float kPIf       = 3.14159265358979323846f;
 
 // ------------------------------------------------------------------ float3 ----
@@ -118,6 +138,32 @@ __device__ __forceinline__ bool tri_test(const f3& o, const f3& d, const f3& v0,
     t_out = t;
     return ok;
 }
+
+// Same test, with the division (the only expensive operation) issued only for lanes that passed
+// the barycentric test; accepted hits are bit-identical to tri_test().
+__device__ __forceinline__ bool tri_test_lazy(const f3& o, const f3& d, const f3& v0, const f3& e1, const f3& e2,
+                                              float tmin, float tmax, float& t_out)
+{
+    f3 p = cross_fma(d, e2);
+    float det = dot_fma(e1, p);
+    f3 s = o - v0;
+    float U = dot_fma(s, p);
+    f3 q = cross_fma(s, e1);
+    float V = dot_fma(d, q);
+    if (det < 0.0f) { det = -det; U = -U; V = -V; p = -p; q = -q; }   // flipping q flips T below
+    bool ok = (det > 0.0f) && !(U < 0.0f || V < 0.0f || U + V > det);
+    t_out = 0.0f;
+    if (ok) {
+        const float T = dot_fma(e2, q);
+        const float t = T / det;
+        ok = (t > tmin && t < tmax);
+        t_out = t;
+    }
+    return ok;
+}
+
+// 1-ulp reciprocal (v_rcp_f32) for quantities outside the bit-exact contract (box tests).
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // ------------------------------------------------------------ LDS lane stack ----
 // One stack per lane, entry-major / lane-minor so a wave-wide push or pop touches 64

@@ -1,0 +1,210 @@
+// pt_shading.h — per-lane shading pieces shared by the render kernels: the reference's sampling,
+// BSDF and colour code restated for gfx950 (plain fp32, no contraction; citations inline).
+#pragma once
+#include "pt_device.h"
+
+namespace ptd {
+
+// sutil/WorkDistribution.h:60-81
+__device__ __forceinline__ void sample_pixel(int num_gpus, int width, int gpu_idx, int sample_idx, int& px, int& py)
+{
+    const int TILE_WIDTH = 8, TILE_HEIGHT = 4;
+    const int tile_strip_width = TILE_WIDTH * num_gpus;
+    const int num_tile_strip_cols = width / tile_strip_width + (width % tile_strip_width == 0 ? 0 : 1);
+    const int tile_strip_idx = sample_idx / (TILE_WIDTH * TILE_HEIGHT);
+    const int tile_strip_y = tile_strip_idx / num_tile_strip_cols;
+    const int tile_strip_x = tile_strip_idx - tile_strip_y * num_tile_strip_cols;
+    const int tile_pixel_idx = sample_idx - tile_strip_idx * (TILE_WIDTH * TILE_HEIGHT);
+    const int tile_pixel_y = tile_pixel_idx / TILE_WIDTH;
+    const int tile_pixel_x = tile_pixel_idx - tile_pixel_y * TILE_WIDTH;
+    const int tile_offset_x = (gpu_idx + tile_strip_y % num_gpus) % num_gpus * TILE_WIDTH;
+    py = tile_strip_y * TILE_HEIGHT + tile_pixel_y;
+    px = tile_strip_x * tile_strip_width + tile_pixel_x + tile_offset_x;
+}
+
+// ---- sampling / BSDF pieces, restated from pathTracerPrograms.cu ---------------------
+// OrthonormalBasis :54-85
+__device__ __forceinline__ void onb_transform(const f3& n, f3& p)
+{
+    f3 bn;
+    if (fabsf(n.x) > fabsf(n.z)) bn = mk(-n.y, n.x, 0.0f);
+    else                         bn = mk(0.0f, -n.z, n.y);
+    bn = normalize(bn);
+    const f3 tg = cross(bn, n);
+    p = p.x * tg + p.y * bn + p.z * n;
+}
+// sampleGGX :455-476 (roughness is the literal 0.2 of :880)
+__device__ __forceinline__ f3 sample_ggx(float u1, float u2, float roughness, const f3& N)
+{
+    const float phi = 2.0f * kPIf * u1;
+    const float cosTheta = sqrtf((1.0f - u2) / (1.0f + (roughness * roughness - 1.0f) * u2));
+    const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+    const f3 H = mk(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta);
+    // :470 compares in double against 0.999; 0.999f rounds up, so the float test is identical
+    const f3 up = fabsf(N.z) < 0.999f ? mk(0.0f, 0.0f, 1.0f) : mk(1.0f, 0.0f, 0.0f);
+    const f3 tangent = normalize(cross(up, N));
+    const f3 bitangent = cross(N, tangent);
+    return normalize(H.x * tangent + H.y * bitangent + H.z * N);
+}
+// fresnelSchlickConductor :494-510
+__device__ __forceinline__ f3 fresnel_conductor(float cosTheta, const f3& eta, const f3& k)
+{
+    const f3 eta2 = eta * eta, k2 = k * k;
+    const f3 c2 = mk(cosTheta * cosTheta);
+    const f3 t1 = eta2 - k2 - c2;
+    const f3 a2plusb2 = mk(sqrtf(t1.x * t1.x + 4 * eta2.x * k2.x), sqrtf(t1.y * t1.y + 4 * eta2.y * k2.y),
+                           sqrtf(t1.z * t1.z + 4 * eta2.z * k2.z));
+    const f3 t2 = a2plusb2 + c2;
+    const f3 Rs = (t2 - 2 * eta * cosTheta + c2) / (t2 + 2 * eta * cosTheta + c2);
+    const f3 Rp = Rs * (t2 - 2 * eta * cosTheta + mk(1.0f)) / (t2 + 2 * eta * cosTheta + mk(1.0f));
+    return (Rs + Rp) * 0.5f;
+}
+// FrDielectric :534-559
+__device__ __forceinline__ float fr_dielectric(float cosThetaI, float etaI, float etaT)
+{
+    cosThetaI = clampf(cosThetaI, -1.0f, 1.0f);
+    if (!(cosThetaI > 0.0f)) { const float t = etaI; etaI = etaT; etaT = t; cosThetaI = fabsf(cosThetaI); }
+    const float sinThetaI = sqrtf(fmaxf(0.0f, 1.0f - cosThetaI * cosThetaI));
+    const float sinThetaT = etaI / etaT * sinThetaI;
+    if (sinThetaT >= 1.0f) return 1.0f;
+    const float cosThetaT = sqrtf(fmaxf(0.0f, 1.0f - sinThetaT * sinThetaT));
+    const float rParl = ((etaT * cosThetaI) - (etaI * cosThetaT)) / ((etaT * cosThetaI) + (etaI * cosThetaT));
+    const float rPerp = ((etaI * cosThetaI) - (etaT * cosThetaT)) / ((etaI * cosThetaI) + (etaT * cosThetaT));
+    return (rParl * rParl + rPerp * rPerp) / 2.0f;
+}
+// refract, cuda/helpers.h:107-137
+__device__ __forceinline__ bool refract_dir(f3& r, const f3& i, const f3& n, float ior)
+{
+    f3 nn = n;
+    float negNdotV = dot(i, nn);
+    float eta;
+    if (negNdotV > 0.0f) { eta = ior; nn = -n; negNdotV = -negNdotV; }
+    else                 { eta = 1.f / ior; }
+    const float k = 1.f - eta * eta * (1.f - negNdotV * negNdotV);
+    if (k < 0.0f) { r = mk(0.f); return false; }
+    r = normalize(eta * i - (eta * negNdotV + sqrtf(k)) * nn);
+    return true;
+}
+__device__ __forceinline__ float safe_div(float a, float b) { return b == 0.0f ? 0.0f : a / b; }
+
+// make_color, cuda/helpers.h:35-62
+__device__ __forceinline__ float to_srgb1(float c)
+{
+    const float invGamma = 1.0f / 2.4f;
+    const float powed = powf(c, invGamma);
+    return c < 0.0031308f ? 12.92f * c : 1.055f * powed - 0.055f;
+}
+__device__ __forceinline__ uint32_t quantize8(float x)
+{
+    x = clampf(x, 0.0f, 1.0f);
+    const uint32_t v = (uint32_t)(x * 256.0f);
+    return v < 255u ? v : 255u;
+}
+__device__ __forceinline__ uint32_t make_color(const f3& c)
+{
+    const uint32_t r = quantize8(to_srgb1(clampf(c.x, 0.0f, 1.0f)));
+    const uint32_t g = quantize8(to_srgb1(clampf(c.y, 0.0f, 1.0f)));
+    const uint32_t b = quantize8(to_srgb1(clampf(c.z, 0.0f, 1.0f)));
+    return r | (g << 8) | (b << 16) | (255u << 24);
+}
+
+__device__ __forceinline__ uint32_t xcc_id()
+{
+    // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4); only used as an affinity hint
+    return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;
+}
+
+
+// Launch constants the shading needs, hoisted once per wave.
+struct ShadeConsts {
+    f3 Lc, Lv1, Lv2, Ln, Le;
+    float lightA;
+    uint32_t useDL, useIS;
+};
+
+// What a closest-hit leaves behind for raygen (RadiancePayloadRayData, pathTracer.h:19-32), minus
+// what is consumed on the spot.
+struct Pending {
+    f3 nxt_org, nxt_dir, radiance;
+    float weight;     // NEE contribution factor if the shadow ray is unoccluded
+    bool done;
+};
+
+// __closesthit__diffuse__ch, pathTracerPrograms.cu:866-1031, for one lane.  Returns true when a
+// shadow ray (P, L, 0.01, Ldist - 0.01) has to be traced before the segment can be accounted.
+__device__ __forceinline__ bool shade_hit(const DeviceScene& sc, const ShadeConsts& K, const f3& org, const f3& dir,
+                                          float t_hit, int slot, int depth, uint32_t& pseed, f3& att, f3& emission,
+                                          Pending& pd, f3& P, f3& L, float& Ldist)
+{
+    const TriRecord* tp = sc.tris + slot;
+    const float4 r0 = tp->r0, r1 = tp->r1, r2 = tp->r2;
+    const pt_material* mp = sc.mats + __float_as_uint(r2.z);
+    const f3 Kd = mk(mp->diffuse), Ke = mk(mp->emission);
+    const float IOR = mp->ior;
+    const int bsdf = mp->bsdfType;
+    const f3 N0 = normalize(cross(mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x)));   // :890
+    const f3 N = faceforward(N0, -dir, N0);
+    P = org + t_hit * dir;                                                       // :894
+    emission = depth == 0 ? Ke : mk(0.0f);                                       // :898-901
+    uint32_t s = pseed;
+    pd.nxt_org = org; pd.nxt_dir = dir;
+    if (bsdf == PT_BSDF_DIFFUSE) {                                               // :907-930
+        const float z1 = rnd(s);
+        const float z2 = rnd(s);
+        f3 w_in;
+        if (K.useIS) {                                                           // :341-353
+            const float theta = acosf(sqrtf(z1));
+            const float phi = 2.0f * kPIf * z2;
+            w_in = mk(sinf(theta) * cosf(phi), sinf(theta) * sinf(phi), cosf(theta));
+        } else {                                                                 // :368-380
+            const float phi = 2.0f * kPIf * z2;
+            w_in = mk(cosf(phi) * sqrtf(1 - z1 * z1), sinf(phi) * sqrtf(1 - z1 * z1), z1);
+        }
+        onb_transform(N, w_in);
+        pd.nxt_dir = w_in;
+        pd.nxt_org = P;
+        att *= Kd;
+    } else if (bsdf == PT_BSDF_METALLIC) {                                       // :931-953
+        const float z1 = rnd(s);
+        const float z2 = rnd(s);
+        const f3 mn = sample_ggx(z1, z2, 0.2f, N);
+        const f3 R = reflect(dir, mn);
+        pd.nxt_dir = R;
+        pd.nxt_org = P + R * 1e-4f;
+        const f3 eta = mk(1.45f, 0.7f, 1.55f), kk = mk(3.0f, 2.2f, 3.5f);
+        const float cosTheta = fmaxf(dot(mn, -dir), 0.0f);
+        const f3 F = fresnel_conductor(cosTheta, eta, kk);
+        att *= F * Kd;
+    } else if (bsdf == PT_BSDF_REFRACTION) {                                     // :954-982
+        const f3 inc = normalize(dir);
+        const float cos_theta = dot(normalize(-dir), N0);
+        const float F = fr_dielectric(cos_theta, 1.0f, IOR);
+        if (rnd(s) < F) {
+            pd.nxt_dir = reflect(inc, N0);
+        } else {
+            f3 rd;
+            pd.nxt_dir = refract_dir(rd, inc, N0, IOR) ? rd : reflect(inc, N0);
+        }
+        pd.nxt_org = P + pd.nxt_dir * 1e-3f;
+        att *= Kd;
+    }
+    const float z1 = rnd(s);                                                     // :985-987
+    const float z2 = rnd(s);
+    pseed = s;
+    if (length(Ke) > 0.0f) { pd.radiance = Ke; pd.done = true; }                 // :992-1000
+    else                   { pd.radiance = mk(0.0f); pd.done = false; }
+    pd.weight = 0.0f;
+    bool want_shadow = false;
+    if (K.useDL && bsdf != PT_BSDF_REFRACTION) {                                 // :1003-1026
+        const f3 light_pos = K.Lc + K.Lv1 * z1 + K.Lv2 * z2;
+        Ldist = length(light_pos - P);
+        L = normalize(light_pos - P);
+        const float nDl = dot(N, L);
+        const float LnDl = -dot(K.Ln, L);
+        want_shadow = nDl > 0.0f && LnDl > 0.0f;
+        pd.weight = nDl * LnDl * K.lightA / (kPIf * Ldist * Ldist);              // :1022, used only if unoccluded
+    }
+    return want_shadow;
+}
+
+}  // namespace ptd

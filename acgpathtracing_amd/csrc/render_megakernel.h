@@ -5,7 +5,8 @@
 
 namespace ptd {
 
-constexpr int kRenderThreads = 256;   // 4 waves per workgroup
+constexpr int kRenderThreads = 256;   // 4 waves per workgroup (segment-synchronous variant)
+constexpr int kDefaultVariant = 6;    // persistent traversal, K40 L8, fp32 nodes, 5 waves/SIMD
 
 struct RenderArgs {
     DeviceScene scene;
@@ -19,12 +20,16 @@ struct RenderArgs {
     uint32_t  total_samples;   // StaticWorkDistribution::numSamples for `world`
     uint32_t  shard_size;      // queue shard length (8 shards)
     uint32_t* queue_heads;     // 8 counters, zeroed before the launch
-    unsigned long long* counters;   // radiance rays, shadow rays, paths, pixels
+    unsigned long long* counters;   // [8] radiance rays, shadow rays, paths, pixels, traversal wave-steps, lane-steps, shade rounds, shade lanes
     uint32_t  stack_entries;
+    uint32_t  n_lds_nodes;     // nodes staged into LDS (NODE_FMT 2), else 0
 };
 
-hipError_t render_occupancy(uint32_t stack_entries, int* blocks_per_cu);
-hipError_t launch_render(const RenderArgs& args, uint32_t grid_blocks, hipStream_t stream);
+int render_variant_count();
+const char* render_variant_name(int variant);
+int render_variant_threads(int variant);
+hipError_t render_occupancy(int variant, uint32_t stack_entries, uint32_t n_nodes, int* blocks_per_cu);
+hipError_t launch_render(int variant, const RenderArgs& args, uint32_t grid_blocks, hipStream_t stream);
 hipError_t launch_resolve(const float4* accum, uint32_t* fb, uint32_t n, hipStream_t stream);
 hipError_t launch_trace_closest(const DeviceScene& sc, uint32_t stack_entries, const float* d_rays, uint32_t n,
                                 float* d_t, uint32_t* d_prim, hipStream_t stream);

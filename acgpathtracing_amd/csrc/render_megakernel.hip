@@ -21,120 +21,84 @@
 // (rank, world), which is also the multi-GPU partition.
 #include "pt_device.h"
 #include "render_megakernel.h"
+#include "pt_shading.h"
 
 namespace ptd {
 
-// sutil/WorkDistribution.h:60-81
-__device__ __forceinline__ void sample_pixel(int num_gpus, int width, int gpu_idx, int sample_idx, int& px, int& py)
-{
-    const int TILE_WIDTH = 8, TILE_HEIGHT = 4;
-    const int tile_strip_width = TILE_WIDTH * num_gpus;
-    const int num_tile_strip_cols = width / tile_strip_width + (width % tile_strip_width == 0 ? 0 : 1);
-    const int tile_strip_idx = sample_idx / (TILE_WIDTH * TILE_HEIGHT);
-    const int tile_strip_y = tile_strip_idx / num_tile_strip_cols;
-    const int tile_strip_x = tile_strip_idx - tile_strip_y * num_tile_strip_cols;
-    const int tile_pixel_idx = sample_idx - tile_strip_idx * (TILE_WIDTH * TILE_HEIGHT);
-    const int tile_pixel_y = tile_pixel_idx / TILE_WIDTH;
-    const int tile_pixel_x = tile_pixel_idx - tile_pixel_y * TILE_WIDTH;
-    const int tile_offset_x = (gpu_idx + tile_strip_y % num_gpus) % num_gpus * TILE_WIDTH;
-    py = tile_strip_y * TILE_HEIGHT + tile_pixel_y;
-    px = tile_strip_x * tile_strip_width + tile_pixel_x + tile_offset_x;
-}
-
-// ---- sampling / BSDF pieces, restated from pathTracerPrograms.cu ---------------------
-// OrthonormalBasis :54-85
-__device__ __forceinline__ void onb_transform(const f3& n, f3& p)
-{
-    f3 bn;
-    if (fabsf(n.x) > fabsf(n.z)) bn = mk(-n.y, n.x, 0.0f);
-    else                         bn = mk(0.0f, -n.z, n.y);
-    bn = normalize(bn);
-    const f3 tg = cross(bn, n);
-    p = p.x * tg + p.y * bn + p.z * n;
-}
-// sampleGGX :455-476 (roughness is the literal 0.2 of :880)
-__device__ __forceinline__ f3 sample_ggx(float u1, float u2, float roughness, const f3& N)
-{
-    const float phi = 2.0f * kPIf * u1;
-    const float cosTheta = sqrtf((1.0f - u2) / (1.0f + (roughness * roughness - 1.0f) * u2));
-    const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
-    const f3 H = mk(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta);
-    // :470 compares in double against 0.999; 0.999f rounds up, so the float test is identical
-    const f3 up = fabsf(N.z) < 0.999f ? mk(0.0f, 0.0f, 1.0f) : mk(1.0f, 0.0f, 0.0f);
-    const f3 tangent = normalize(cross(up, N));
-    const f3 bitangent = cross(N, tangent);
-    return normalize(H.x * tangent + H.y * bitangent + H.z * N);
-}
-// fresnelSchlickConductor :494-510
-__device__ __forceinline__ f3 fresnel_conductor(float cosTheta, const f3& eta, const f3& k)
-{
-    const f3 eta2 = eta * eta, k2 = k * k;
-    const f3 c2 = mk(cosTheta * cosTheta);
-    const f3 t1 = eta2 - k2 - c2;
-    const f3 a2plusb2 = mk(sqrtf(t1.x * t1.x + 4 * eta2.x * k2.x), sqrtf(t1.y * t1.y + 4 * eta2.y * k2.y),
-                           sqrtf(t1.z * t1.z + 4 * eta2.z * k2.z));
-    const f3 t2 = a2plusb2 + c2;
-    const f3 Rs = (t2 - 2 * eta * cosTheta + c2) / (t2 + 2 * eta * cosTheta + c2);
-    const f3 Rp = Rs * (t2 - 2 * eta * cosTheta + mk(1.0f)) / (t2 + 2 * eta * cosTheta + mk(1.0f));
-    return (Rs + Rp) * 0.5f;
-}
-// FrDielectric :534-559
-__device__ __forceinline__ float fr_dielectric(float cosThetaI, float etaI, float etaT)
-{
-    cosThetaI = clampf(cosThetaI, -1.0f, 1.0f);
-    if (!(cosThetaI > 0.0f)) { const float t = etaI; etaI = etaT; etaT = t; cosThetaI = fabsf(cosThetaI); }
-    const float sinThetaI = sqrtf(fmaxf(0.0f, 1.0f - cosThetaI * cosThetaI));
-    const float sinThetaT = etaI / etaT * sinThetaI;
-    if (sinThetaT >= 1.0f) return 1.0f;
-    const float cosThetaT = sqrtf(fmaxf(0.0f, 1.0f - sinThetaT * sinThetaT));
-    const float rParl = ((etaT * cosThetaI) - (etaI * cosThetaT)) / ((etaT * cosThetaI) + (etaI * cosThetaT));
-    const float rPerp = ((etaI * cosThetaI) - (etaT * cosThetaT)) / ((etaI * cosThetaI) + (etaT * cosThetaT));
-    return (rParl * rParl + rPerp * rPerp) / 2.0f;
-}
-// refract, cuda/helpers.h:107-137
-__device__ __forceinline__ bool refract_dir(f3& r, const f3& i, const f3& n, float ior)
-{
-    f3 nn = n;
-    float negNdotV = dot(i, nn);
-    float eta;
-    if (negNdotV > 0.0f) { eta = ior; nn = -n; negNdotV = -negNdotV; }
-    else                 { eta = 1.f / ior; }
-    const float k = 1.f - eta * eta * (1.f - negNdotV * negNdotV);
-    if (k < 0.0f) { r = mk(0.f); return false; }
-    r = normalize(eta * i - (eta * negNdotV + sqrtf(k)) * nn);
-    return true;
-}
-__device__ __forceinline__ float safe_div(float a, float b) { return b == 0.0f ? 0.0f : a / b; }
-
-// make_color, cuda/helpers.h:35-62
-__device__ __forceinline__ float to_srgb1(float c)
-{
-    const float invGamma = 1.0f / 2.4f;
-    const float powed = powf(c, invGamma);
-    return c < 0.0031308f ? 12.92f * c : 1.055f * powed - 0.055f;
-}
-__device__ __forceinline__ uint32_t quantize8(float x)
-{
-    x = clampf(x, 0.0f, 1.0f);
-    const uint32_t v = (uint32_t)(x * 256.0f);
-    return v < 255u ? v : 255u;
-}
-__device__ __forceinline__ uint32_t make_color(const f3& c)
-{
-    const uint32_t r = quantize8(to_srgb1(clampf(c.x, 0.0f, 1.0f)));
-    const uint32_t g = quantize8(to_srgb1(clampf(c.y, 0.0f, 1.0f)));
-    const uint32_t b = quantize8(to_srgb1(clampf(c.z, 0.0f, 1.0f)));
-    return r | (g << 8) | (b << 16) | (255u << 24);
-}
-
-__device__ __forceinline__ uint32_t xcc_id()
-{
-    // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4); only used as an affinity hint
-    return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;
-}
-
 extern __shared__ uint32_t lds_dyn[];
 
+// ---- pixel queue: ballot the idle lanes, one atomic by the first of them, prefix-popcount ----
+struct QueueState { uint32_t shard, shards_left; };
+
+struct LanePixel {
+    bool alive, new_path;
+    uint32_t pix, px, py, seed, samples_left;
+    f3 result;
+};
+
+__device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q, uint32_t lane, unsigned long long below, LanePixel& lp)
+{
+    unsigned long long idle = __ballot(!lp.alive);
+    while (idle != 0ull && q.shards_left != 0u) {
+        const uint32_t want = (uint32_t)__popcll(idle);
+        const uint32_t leader = (uint32_t)__ffsll((long long)idle) - 1u;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&A.queue_heads[q.shard], want);
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);   // wave-uniform
+        const uint32_t shard_begin = q.shard * A.shard_size;
+        uint32_t shard_end = shard_begin + A.shard_size;
+        if (shard_end > A.total_samples) shard_end = A.total_samples;
+        if (shard_begin > A.total_samples) shard_end = shard_begin;
+        const uint32_t first = shard_begin + base;
+        const uint32_t avail = first < shard_end ? shard_end - first : 0u;
+        if (!lp.alive) {
+            const uint32_t rank = (uint32_t)__popcll(idle & below);
+            if (rank < avail) {
+                int x, y;
+                sample_pixel(A.world, (int)A.width, A.rank, (int)(first + rank), x, y);
+                if ((uint32_t)x < A.width && (uint32_t)y < A.height) {
+                    lp.px = (uint32_t)x; lp.py = (uint32_t)y;
+                    lp.pix = lp.py * A.width + lp.px;
+                    lp.seed = tea4(lp.pix, A.frame);                  // :721
+                    lp.result = mk(0.0f);
+                    lp.samples_left = A.spp;
+                    lp.alive = true;
+                    lp.new_path = true;
+                }
+            }
+        }
+        if (avail < want) { q.shard = (q.shard + 1u) & 7u; q.shards_left--; }   // shard drained: steal from the next
+        idle = __ballot(!lp.alive);
+        if (avail >= want) break;   // everyone who asked was served (padding pixels retry next turn)
+    }
+}
+
+// pixel finished: mean over spp, progressive lerp, float4 + sRGB write (:782-814)
+__device__ __forceinline__ void write_pixel(const RenderArgs& A, uint32_t pix, const f3& result)
+{
+    f3 accum = result / (float)A.spp;
+    if (A.frame > 0u) {
+        const float a = 1.0f / (float)(A.frame + 1u);
+        const float4 prev = A.accum[pix];
+        accum = lerp3(mk(prev.x, prev.y, prev.z), accum, a);
+    }
+    A.accum[pix] = make_float4(accum.x, accum.y, accum.z, 1.0f);
+    if (A.fb) A.fb[pix] = make_color(accum);
+}
+
+__device__ __forceinline__ ShadeConsts shade_consts(const RenderArgs& A)
+{
+    ShadeConsts K;
+    K.Lc = mk(A.light.corner); K.Lv1 = mk(A.light.v1); K.Lv2 = mk(A.light.v2); K.Ln = mk(A.light.normal); K.Le = mk(A.light.emission);
+    K.lightA = length(cross(K.Lv1, K.Lv2));                         // :1021
+    K.useDL = A.useDL; K.useIS = A.useIS;
+    return K;
+}
+
+// =================================================================================================
+// Variant 0: segment-synchronous.  Every iteration: all live lanes trace one radiance segment to
+// completion, shade, (some) trace a shadow ray, account.  Simple; lanes wait for the slowest ray.
+// =================================================================================================
 __global__ void __launch_bounds__(kRenderThreads)
 k_render(const RenderArgs A)
 {
@@ -143,199 +107,75 @@ k_render(const RenderArgs A)
     LaneStack st;
     st.base = lds_dyn + wave * (A.stack_entries * 64u) + lane;
     const DeviceScene sc = A.scene;
-
+    const ShadeConsts K = shade_consts(A);
     const f3 eye = mk(A.eye), camU = mk(A.U), camV = mk(A.V), camW = mk(A.W);
-    const f3 Lc = mk(A.light.corner), Lv1 = mk(A.light.v1), Lv2 = mk(A.light.v2), Ln = mk(A.light.normal), Le = mk(A.light.emission);
-    const float lightA = length(cross(Lv1, Lv2));                    // :1021
     const float fw = (float)(int)A.width, fh = (float)(int)A.height;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-    // queue state (wave-uniform)
-    uint32_t shard = xcc_id();
-    uint32_t shards_left = 8;
-    // counters (wave-uniform, flushed once)
+    QueueState q; q.shard = xcc_id(); q.shards_left = 8;
     unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0;
 
-    // lane state
-    bool alive = false, new_path = false;
-    uint32_t pix = 0, px = 0, py = 0, seed = 0, pseed = 0, samples_left = 0;
+    LanePixel lp; lp.alive = false; lp.new_path = false; lp.pix = lp.px = lp.py = lp.seed = lp.samples_left = 0; lp.result = mk(0.0f);
+    uint32_t pseed = 0;
     int depth = 0;
-    f3 result = mk(0.0f), org = mk(0.0f), dir = mk(0.0f, 0.0f, 1.0f), att = mk(1.0f);
+    f3 org = mk(0.0f), dir = mk(0.0f, 0.0f, 1.0f), att = mk(1.0f);
 
     for (;;) {
-        // ---- refill idle lanes from the pixel queue --------------------------------
-        unsigned long long idle = __ballot(!alive);
-        while (idle != 0ull && shards_left != 0u) {
-            const uint32_t want = (uint32_t)__popcll(idle);
-            const uint32_t leader = (uint32_t)__ffsll((long long)idle) - 1u;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&A.queue_heads[shard], want);
-            base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);   // wave-uniform
-            const uint32_t shard_begin = shard * A.shard_size;
-            uint32_t shard_end = shard_begin + A.shard_size;
-            if (shard_end > A.total_samples) shard_end = A.total_samples;
-            if (shard_begin > A.total_samples) shard_end = shard_begin;
-            const uint32_t first = shard_begin + base;
-            const uint32_t avail = first < shard_end ? shard_end - first : 0u;
-            if (!alive) {
-                const uint32_t rank = (uint32_t)__popcll(idle & below);
-                if (rank < avail) {
-                    int x, y;
-                    sample_pixel(A.world, (int)A.width, A.rank, (int)(first + rank), x, y);
-                    if ((uint32_t)x < A.width && (uint32_t)y < A.height) {
-                        px = (uint32_t)x; py = (uint32_t)y;
-                        pix = py * A.width + px;
-                        seed = tea4(pix, A.frame);                       // :721
-                        result = mk(0.0f);
-                        samples_left = A.spp;
-                        alive = true;
-                        new_path = true;
-                    }
-                }
-            }
-            if (avail < want) { shard = (shard + 1u) & 7u; shards_left--; }   // shard drained: steal next
-            idle = __ballot(!alive);
-            if (avail >= want) break;   // everyone asked was served (padding pixels stay idle till next turn)
-        }
-        const unsigned long long live = __ballot(alive);
-        if (live == 0ull) { if (shards_left == 0u) break; else continue; }
+        refill_lanes(A, q, lane, below, lp);
+        const unsigned long long live = __ballot(lp.alive);
+        if (live == 0ull) { if (q.shards_left == 0u) break; else continue; }
 
-        // ---- camera path start, :727-745 ---------------------------------------------
-        if (alive && new_path) {
-            const float jx = rnd(seed);
-            const float jy = rnd(seed);
-            const float dx = 2.0f * (((float)px + jx) / fw) - 1.0f;
-            const float dy = 2.0f * (((float)py + jy) / fh) - 1.0f;
+        if (lp.alive && lp.new_path) {                                // camera path start, :727-745
+            const float jx = rnd(lp.seed);
+            const float jy = rnd(lp.seed);
+            const float dx = 2.0f * (((float)lp.px + jx) / fw) - 1.0f;
+            const float dy = 2.0f * (((float)lp.py + jy) / fh) - 1.0f;
             dir = normalize(dx * camU + dy * camV + camW);
             org = eye;
             att = mk(1.0f);
-            pseed = seed;
+            pseed = lp.seed;
             depth = 0;
-            new_path = false;
+            lp.new_path = false;
         }
 
-        // ---- radiance segment: closest hit, tmin 0.01, tmax 1e16 (:750-757) -----------
-        HitRec hit;
-        traverse<false>(sc, st, alive, org, dir, 0.01f, 1e16f, hit);
+        HitRec hit;                                                   // radiance segment (:750-757)
+        traverse<false>(sc, st, lp.alive, org, dir, 0.01f, 1e16f, hit);
         n_radiance += (unsigned long long)__popcll(live);
 
-        f3 emission = mk(0.0f), radiance = mk(0.0f), P = mk(0.0f), N = mk(0.0f), new_org = org, new_dir = dir;
-        bool done = true;             // __miss__ms :833-847: radiance = background (0), done
+        f3 emission = mk(0.0f), P = mk(0.0f), L = mk(0.0f);
+        float Ldist = 0.0f;
+        Pending pd; pd.nxt_org = org; pd.nxt_dir = dir; pd.radiance = mk(0.0f); pd.weight = 0.0f;
+        pd.done = true;                                               // __miss__ms :833-847
         bool want_shadow = false;
-        f3 L = mk(0.0f); float Ldist = 0.0f, nDl = 0.0f, LnDl = 0.0f;
-        const bool is_hit = alive && hit.slot >= 0;
-        if (is_hit) {
-            // ---- __closesthit__diffuse__ch :866-1031 -----------------------------------
-            const TriRecord* tp = sc.tris + hit.slot;
-            const float4 r0 = tp->r0, r1 = tp->r1, r2 = tp->r2;
-            const pt_material* mp = sc.mats + __float_as_uint(r2.z);
-            const f3 Kd = mk(mp->diffuse), Ke = mk(mp->emission);
-            const float IOR = mp->ior;
-            const int bsdf = mp->bsdfType;
-            const f3 N0 = normalize(cross(mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x)));   // :890
-            N = faceforward(N0, -dir, N0);
-            P = org + hit.t * dir;                                                       // :894
-            emission = depth == 0 ? Ke : mk(0.0f);                                       // :898-901
-            uint32_t s = pseed;
-            if (bsdf == PT_BSDF_DIFFUSE) {                                               // :907-930
-                const float z1 = rnd(s);
-                const float z2 = rnd(s);
-                f3 w_in;
-                if (A.useIS) {                                                           // :341-353
-                    const float theta = acosf(sqrtf(z1));
-                    const float phi = 2.0f * kPIf * z2;
-                    w_in = mk(sinf(theta) * cosf(phi), sinf(theta) * sinf(phi), cosf(theta));
-                } else {                                                                 // :368-380
-                    const float phi = 2.0f * kPIf * z2;
-                    w_in = mk(cosf(phi) * sqrtf(1 - z1 * z1), sinf(phi) * sqrtf(1 - z1 * z1), z1);
-                }
-                onb_transform(N, w_in);
-                new_dir = w_in;
-                new_org = P;
-                att *= Kd;
-            } else if (bsdf == PT_BSDF_METALLIC) {                                       // :931-953
-                const float z1 = rnd(s);
-                const float z2 = rnd(s);
-                const f3 mn = sample_ggx(z1, z2, 0.2f, N);
-                const f3 R = reflect(dir, mn);
-                new_dir = R;
-                new_org = P + R * 1e-4f;
-                const f3 eta = mk(1.45f, 0.7f, 1.55f), kk = mk(3.0f, 2.2f, 3.5f);
-                const float cosTheta = fmaxf(dot(mn, -dir), 0.0f);
-                const f3 F = fresnel_conductor(cosTheta, eta, kk);
-                att *= F * Kd;
-            } else if (bsdf == PT_BSDF_REFRACTION) {                                     // :954-982
-                const f3 inc = normalize(dir);
-                const float cos_theta = dot(normalize(-dir), N0);
-                const float F = fr_dielectric(cos_theta, 1.0f, IOR);
-                if (rnd(s) < F) {
-                    new_dir = reflect(inc, N0);
-                } else {
-                    f3 rd;
-                    new_dir = refract_dir(rd, inc, N0, IOR) ? rd : reflect(inc, N0);
-                }
-                new_org = P + new_dir * 1e-3f;
-                att *= Kd;
-            }
-            const float z1 = rnd(s);                                                     // :985-987
-            const float z2 = rnd(s);
-            pseed = s;
-            if (length(Ke) > 0.0f) { radiance = Ke; done = true; }                       // :992-1000
-            else                   { radiance = mk(0.0f); done = false; }
-            if (A.useDL && bsdf != PT_BSDF_REFRACTION) {                                 // :1003-1026
-                const f3 light_pos = Lc + Lv1 * z1 + Lv2 * z2;
-                Ldist = length(light_pos - P);
-                L = normalize(light_pos - P);
-                nDl = dot(N, L);
-                LnDl = -dot(Ln, L);
-                want_shadow = nDl > 0.0f && LnDl > 0.0f;
-            }
-        }
+        if (lp.alive && hit.slot >= 0)
+            want_shadow = shade_hit(sc, K, org, dir, hit.t, hit.slot, depth, pseed, att, emission, pd, P, L, Ldist);
 
-        // ---- occlusion ray (traceOcclusion :651-684): any hit occludes -----------------
         const unsigned long long shadow_mask = __ballot(want_shadow);
-        if (shadow_mask != 0ull) {
+        if (shadow_mask != 0ull) {                                    // traceOcclusion :651-684
             HitRec sh;
             const bool occluded = traverse<true>(sc, st, want_shadow, P, L, 0.01f, Ldist - 0.01f, sh);
             n_shadow += (unsigned long long)__popcll(shadow_mask);
-            if (want_shadow && !occluded) {
-                const float weight = nDl * LnDl * lightA / (kPIf * Ldist * Ldist);
-                radiance += Le * weight;
-            }
+            if (want_shadow && !occluded) pd.radiance += K.Le * pd.weight;
         }
 
-        // ---- back in raygen: accumulate, roulette, advance (:760-778) ------------------
         bool end = false, finished = false;
-        if (alive) {
-            result += emission;
-            result += radiance * att;
+        if (lp.alive) {                                               // raygen :760-778
+            lp.result += emission;
+            lp.result += pd.radiance * att;
             const float p = dot(att, mk(0.30f, 0.59f, 0.11f));
             const bool rr = rnd(pseed) > p;
-            end = done || rr || (uint32_t)depth >= A.maxDepth;
+            end = pd.done || rr || (uint32_t)depth >= A.maxDepth;
             if (!end) {
                 att = mk(safe_div(att.x, p), safe_div(att.y, p), safe_div(att.z, p));
-                org = new_org;
-                dir = new_dir;
+                org = pd.nxt_org;
+                dir = pd.nxt_dir;
                 ++depth;
             } else {
-                samples_left--;
-                new_path = true;
-                if (samples_left == 0u) {
-                    // ---- pixel finished (:782-814) ---------------------------------------
-                    f3 accum = result / (float)A.spp;
-                    if (A.frame > 0u) {
-                        const float a = 1.0f / (float)(A.frame + 1u);
-                        const float4 prev = A.accum[pix];
-                        accum = lerp3(mk(prev.x, prev.y, prev.z), accum, a);
-                    }
-                    A.accum[pix] = make_float4(accum.x, accum.y, accum.z, 1.0f);
-                    if (A.fb) A.fb[pix] = make_color(accum);
-                    alive = false;
-                    finished = true;
-                }
+                lp.samples_left--;
+                lp.new_path = true;
+                if (lp.samples_left == 0u) { write_pixel(A, lp.pix, lp.result); lp.alive = false; finished = true; }
             }
         }
-        // wave-uniform counters: ballots taken with the whole wave converged
         n_paths += (unsigned long long)__popcll(__ballot(end));
         n_pixels += (unsigned long long)__popcll(__ballot(finished));
     }
@@ -345,6 +185,246 @@ k_render(const RenderArgs A)
         atomicAdd(&A.counters[2], n_paths);
         atomicAdd(&A.counters[3], n_pixels);
     }
+}
+
+// =================================================================================================
+// Variant 1: persistent traversal with deferred shading.  The BVH loop never waits for the slowest
+// ray: a lane whose ray is finished parks; once SHADE_K lanes are parked (or nothing is left to
+// traverse) the wave leaves the traversal loop, shades exactly those lanes — closest-hit, shadow
+// resolve, roulette, next camera path or next pixel from the queue — gives each of them a new ray
+// and re-enters the loop.  Radiance and shadow rays share the one traversal loop (a per-lane
+// any-hit flag).  Each lane still performs its own operations in the reference's order, so the
+// image is bit-identical to variant 0; only the interleaving between lanes changes.
+// LEAF_K: triangle tests run when at least LEAF_K lanes sit at a leaf, or no lane has an inner node.
+// =================================================================================================
+// NODE_FMT: 0 = fp32 boxes, 64-byte nodes in global memory (4 x 16-byte loads per visit)
+//           1 = 16-bit grid boxes, 32-byte nodes in global memory (2 loads per visit)
+//           2 = the same 32-byte nodes staged into LDS by each workgroup (scenes whose node array
+//               fits beside the lane stacks; 1024-thread workgroups so one copy serves 16 waves)
+template <int SHADE_K, int LEAF_K, int NODE_FMT, int THREADS, int MINW, bool STATS>
+__global__ void __launch_bounds__(THREADS, MINW)
+k_render_pw(const RenderArgs A)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    LaneStack st;
+    st.base = lds_dyn + wave * (A.stack_entries * 64u) + lane;
+    const DeviceScene sc = A.scene;
+    const uint2* lds_nodes = (const uint2*)(lds_dyn + (THREADS / 64) * (A.stack_entries * 64u));
+    if (NODE_FMT == 2) {
+        uint4* dst = (uint4*)(lds_dyn + (THREADS / 64) * (A.stack_entries * 64u));
+        const uint4* src = (const uint4*)sc.qnodes;
+        for (uint32_t i = threadIdx.x; i < A.n_lds_nodes * 2u; i += THREADS) dst[i] = src[i];
+        __syncthreads();
+    }
+    const QGrid G = sc.grid;
+    const ShadeConsts K = shade_consts(A);
+    const f3 eye = mk(A.eye), camU = mk(A.U), camV = mk(A.V), camW = mk(A.W);
+    const float fw = (float)(int)A.width, fh = (float)(int)A.height;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int root = sc.n_tris ? 0 : kSentinel;
+
+    QueueState q; q.shard = xcc_id(); q.shards_left = 8;
+    unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0;
+    unsigned long long n_steps = 0, n_lane_steps = 0, n_rounds = 0, n_lane_rounds = 0;
+
+    LanePixel lp; lp.alive = false; lp.new_path = false; lp.pix = lp.px = lp.py = lp.seed = lp.samples_left = 0; lp.result = mk(0.0f);
+    uint32_t pseed = 0;
+    int depth = 0;
+    f3 att = mk(1.0f);
+    // ray in flight (rinv / gro: reciprocal direction and origin, in grid space for quantised nodes)
+    f3 ro = mk(0.0f), rd = mk(0.0f, 0.0f, 1.0f), rinv = mk(1.0f), gro = mk(0.0f);
+    float rtmin = 0.0f, rtmax = 0.0f, best_t = 0.0f;
+    int best_slot = -1; uint32_t best_prim = 0xFFFFFFFFu;
+    int node = kSentinel, sp = 0;
+    bool shadow_ray = false, shadow_hit = false;
+    // held while the shadow ray is in flight
+    Pending pd; pd.nxt_org = mk(0.0f); pd.nxt_dir = mk(0.0f, 0.0f, 1.0f); pd.radiance = mk(0.0f); pd.weight = 0.0f; pd.done = true;
+
+    for (;;) {
+        // =========================== shade / regenerate: lanes with no ray in flight ===============
+        if (STATS) { n_rounds += 1; n_lane_rounds += (unsigned long long)__popcll(__ballot(lp.alive && node == kSentinel)); }
+        bool segment_done = false, started_shadow = false;
+        f3 emission = mk(0.0f);
+        if (lp.alive && node == kSentinel) {
+            if (shadow_ray) {                                         // shadow ray back (:1015-1024)
+                if (!shadow_hit) pd.radiance += K.Le * pd.weight;
+                shadow_ray = false;
+                segment_done = true;
+            } else {                                                  // radiance ray back
+                bool want_shadow = false;
+                f3 P, L; float Ldist;
+                if (best_slot >= 0) {
+                    want_shadow = shade_hit(sc, K, ro, rd, best_t, best_slot, depth, pseed, att, emission, pd, P, L, Ldist);
+                } else {                                              // __miss__ms :833-847
+                    pd.radiance = mk(0.0f); pd.weight = 0.0f; pd.done = true;
+                }
+                lp.result += emission;                                // :760 (before the radiance term)
+                if (want_shadow) {
+                    ro = P; rd = L; rinv = mk(fast_rcp(L.x), fast_rcp(L.y), fast_rcp(L.z));
+                    if (NODE_FMT != 0) {
+                        gro = mk((ro.x - G.ox) * G.icx, (ro.y - G.oy) * G.icy, (ro.z - G.oz) * G.icz);
+                        rinv = mk(G.cx * rinv.x, G.cy * rinv.y, G.cz * rinv.z);
+                    }
+                    rtmin = 0.01f; rtmax = Ldist - 0.01f; best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu;
+                    node = root; sp = 0; shadow_ray = true; shadow_hit = false; started_shadow = true;
+                } else {
+                    segment_done = true;
+                }
+            }
+        }
+        n_shadow += (unsigned long long)__popcll(__ballot(started_shadow));
+        bool end = false, finished = false;
+        if (segment_done) {                                           // raygen :761-778
+            lp.result += pd.radiance * att;
+            const float p = dot(att, mk(0.30f, 0.59f, 0.11f));
+            const bool rr = rnd(pseed) > p;
+            end = pd.done || rr || (uint32_t)depth >= A.maxDepth;
+            if (!end) {
+                att = mk(safe_div(att.x, p), safe_div(att.y, p), safe_div(att.z, p));
+                ro = pd.nxt_org; rd = pd.nxt_dir;
+                ++depth;
+            } else {
+                lp.samples_left--;
+                lp.new_path = true;
+                if (lp.samples_left == 0u) { write_pixel(A, lp.pix, lp.result); lp.alive = false; finished = true; }
+            }
+        }
+        n_paths += (unsigned long long)__popcll(__ballot(end));
+        n_pixels += (unsigned long long)__popcll(__ballot(finished));
+
+        refill_lanes(A, q, lane, below, lp);
+        if (__ballot(lp.alive) == 0ull) { if (q.shards_left == 0u) break; else continue; }
+
+        bool start_radiance = segment_done && !end;
+        if (lp.alive && lp.new_path) {                                // camera path start, :727-745
+            const float jx = rnd(lp.seed);
+            const float jy = rnd(lp.seed);
+            const float dx = 2.0f * (((float)lp.px + jx) / fw) - 1.0f;
+            const float dy = 2.0f * (((float)lp.py + jy) / fh) - 1.0f;
+            rd = normalize(dx * camU + dy * camV + camW);
+            ro = eye;
+            att = mk(1.0f);
+            pseed = lp.seed;
+            depth = 0;
+            lp.new_path = false;
+            start_radiance = true;
+        }
+        if (start_radiance) {                                         // traceRadiance :750-757
+            rinv = mk(fast_rcp(rd.x), fast_rcp(rd.y), fast_rcp(rd.z));
+            if (NODE_FMT != 0) {
+                gro = mk((ro.x - G.ox) * G.icx, (ro.y - G.oy) * G.icy, (ro.z - G.oz) * G.icz);
+                rinv = mk(G.cx * rinv.x, G.cy * rinv.y, G.cz * rinv.z);
+            }
+            rtmin = 0.01f; rtmax = 1e16f; best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu;
+            node = root; sp = 0; shadow_ray = false;
+        }
+        n_radiance += (unsigned long long)__popcll(__ballot(start_radiance));
+
+        // =========================== traversal: until SHADE_K lanes are parked =====================
+        for (;;) {
+            const bool act = node != kSentinel;
+            const unsigned long long am = __ballot(act);
+            if (am == 0ull) break;
+            if (__popcll(__ballot(!act && lp.alive)) >= SHADE_K) break;
+            if (STATS) { n_steps += 1; n_lane_steps += (unsigned long long)__popcll(am); }
+            if (act && node >= 0) {
+                float n0, f0, n1, f1; int c0, c1;
+                if (NODE_FMT == 0) {
+                    const BvhNode* np = sc.nodes + node;
+                    const float4 a = np->a, b = np->b, c = np->c;
+                    const int4 ch = np->d;
+                    c0 = ch.x; c1 = ch.y;
+                    float x0 = (a.x - ro.x) * rinv.x, x1 = (a.w - ro.x) * rinv.x;
+                    float y0 = (a.y - ro.y) * rinv.y, y1 = (b.x - ro.y) * rinv.y;
+                    float z0 = (a.z - ro.z) * rinv.z, z1 = (b.y - ro.z) * rinv.z;
+                    n0 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), rtmin));
+                    f0 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1)) * kFarWiden;
+                    float u0 = (b.z - ro.x) * rinv.x, u1 = (c.y - ro.x) * rinv.x;
+                    float v0 = (b.w - ro.y) * rinv.y, v1 = (c.z - ro.y) * rinv.y;
+                    float w0 = (c.x - ro.z) * rinv.z, w1 = (c.w - ro.z) * rinv.z;
+                    n1 = fmaxf(fmaxf(fminf(u0, u1), fminf(v0, v1)), fmaxf(fminf(w0, w1), rtmin));
+                    f1 = fminf(fminf(fmaxf(u0, u1), fmaxf(v0, v1)), fmaxf(w0, w1)) * kFarWiden;
+                } else {
+                    uint4 qa, qb;
+                    if (NODE_FMT == 2) {
+                        const uint2* p = lds_nodes + 4 * node;
+                        const uint2 t0 = p[0], t1 = p[1], t2 = p[2], t3 = p[3];
+                        qa = make_uint4(t0.x, t0.y, t1.x, t1.y); qb = make_uint4(t2.x, t2.y, t3.x, t3.y);
+                    } else {
+                        const QNode* np = sc.qnodes + node;
+                        qa = np->a; qb = np->b;
+                    }
+                    c0 = (int)qa.w; c1 = (int)qb.w;
+                    float x0 = ((float)(qa.x & 0xFFFFu) - gro.x) * rinv.x, x1 = ((float)(qa.y >> 16) - gro.x) * rinv.x;
+                    float y0 = ((float)(qa.x >> 16) - gro.y) * rinv.y, y1 = ((float)(qa.z & 0xFFFFu) - gro.y) * rinv.y;
+                    float z0 = ((float)(qa.y & 0xFFFFu) - gro.z) * rinv.z, z1 = ((float)(qa.z >> 16) - gro.z) * rinv.z;
+                    n0 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), rtmin));
+                    f0 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1)) * kFarWiden;
+                    float u0 = ((float)(qb.x & 0xFFFFu) - gro.x) * rinv.x, u1 = ((float)(qb.y >> 16) - gro.x) * rinv.x;
+                    float v0 = ((float)(qb.x >> 16) - gro.y) * rinv.y, v1 = ((float)(qb.z & 0xFFFFu) - gro.y) * rinv.y;
+                    float w0 = ((float)(qb.y & 0xFFFFu) - gro.z) * rinv.z, w1 = ((float)(qb.z >> 16) - gro.z) * rinv.z;
+                    n1 = fmaxf(fmaxf(fminf(u0, u1), fminf(v0, v1)), fmaxf(fminf(w0, w1), rtmin));
+                    f1 = fminf(fminf(fmaxf(u0, u1), fmaxf(v0, v1)), fmaxf(w0, w1)) * kFarWiden;
+                }
+                f0 = fminf(f0, best_t);
+                f1 = fminf(f1, best_t);
+                const bool h0 = n0 <= f0, h1 = n1 <= f1;
+                if (h0 && h1) {
+                    const bool first0 = n0 <= n1;
+                    st.push(sp, first0 ? c1 : c0);
+                    sp++;
+                    node = first0 ? c0 : c1;
+                } else if (h0) {
+                    node = c0;
+                } else if (h1) {
+                    node = c1;
+                } else {
+                    if (sp == 0) node = kSentinel; else { sp--; node = st.pop(sp); }
+                }
+            }
+            const bool at_leaf = node < 0;       // kSentinel is positive
+            const unsigned long long lm = __ballot(at_leaf);
+            if (lm != 0ull && (LEAF_K <= 1 || __popcll(lm) >= LEAF_K || __ballot(node >= 0 && node != kSentinel) == 0ull)) {
+                if (at_leaf) {
+                    const int slot = ~node;
+                    const TriRecord* tp = sc.tris + slot;
+                    const float4 r0 = tp->r0, r1 = tp->r1, r2 = tp->r2;
+                    float t;
+                    const bool ok = tri_test_lazy(ro, rd, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), rtmin, rtmax, t);
+                    const uint32_t prim = __float_as_uint(r2.y);
+                    bool stop = false;
+                    if (ok) {
+                        if (shadow_ray) { shadow_hit = true; stop = true; }
+                        else if (t < best_t || (t == best_t && prim < best_prim)) { best_t = t; best_slot = slot; best_prim = prim; }
+                    }
+                    if (stop || sp == 0) node = kSentinel; else { sp--; node = st.pop(sp); }
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&A.counters[0], n_radiance);
+        atomicAdd(&A.counters[1], n_shadow);
+        atomicAdd(&A.counters[2], n_paths);
+        atomicAdd(&A.counters[3], n_pixels);
+        atomicAdd(&A.counters[4], n_steps);
+        atomicAdd(&A.counters[5], n_lane_steps);
+        atomicAdd(&A.counters[6], n_rounds);
+        atomicAdd(&A.counters[7], n_lane_rounds);
+    }
+}
+
+__global__ void k_resolve(const float4* __restrict__ accum, uint32_t* __restrict__ fb, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const float4 a = accum[i]; fb[i] = make_color(mk(a.x, a.y, a.z)); }
+}
+
+hipError_t launch_resolve(const float4* accum, uint32_t* fb, uint32_t n, hipStream_t stream)
+{
+    k_resolve<<<(n + 255) / 256, 256, 0, stream>>>(accum, fb, n);
+    return hipGetLastError();
 }
 
 // ---- standalone ray queries (parity tests): same traversal, one ray per lane -------------
@@ -377,31 +457,56 @@ k_trace_any(const DeviceScene sc, uint32_t stack_entries, const float* __restric
     if (active) hit_out[i] = f ? 1 : 0;
 }
 
-__global__ void k_resolve(const float4* __restrict__ accum, uint32_t* __restrict__ fb, uint32_t n)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { const float4 a = accum[i]; fb[i] = make_color(mk(a.x, a.y, a.z)); }
-}
-
-hipError_t launch_resolve(const float4* accum, uint32_t* fb, uint32_t n, hipStream_t stream)
-{
-    k_resolve<<<(n + 255) / 256, 256, 0, stream>>>(accum, fb, n);
-    return hipGetLastError();
-}
-
 // ---- host-side launchers ------------------------------------------------------------------
-hipError_t render_occupancy(uint32_t stack_entries, int* blocks_per_cu)
+typedef void (*RenderKernel)(const RenderArgs);
+
+struct VariantDesc { RenderKernel k; int threads; int node_fmt; const char* name; };
+
+// Render kernel variants.  0: segment-synchronous (fp32 nodes).  Others: persistent traversal
+// <SHADE_K, LEAF_K, NODE_FMT, THREADS>.
+static const VariantDesc kVariants[] = {
+    {k_render, 256, 0, "sync fp32-nodes"},
+    {k_render_pw<32, 8, 0, 256, 4, true>, 256, 0, "pw K32 L8 fp32 w4 stats"},
+    {k_render_pw<32, 8, 0, 256, 4, false>, 256, 0, "pw K32 L8 fp32 w4"},
+    {k_render_pw<32, 8, 0, 256, 5, false>, 256, 0, "pw K32 L8 fp32 w5"},
+    {k_render_pw<32, 8, 0, 256, 6, false>, 256, 0, "pw K32 L8 fp32 w6"},
+    {k_render_pw<32, 8, 0, 256, 8, false>, 256, 0, "pw K32 L8 fp32 w8"},
+    {k_render_pw<40, 8, 0, 256, 5, false>, 256, 0, "pw K40 L8 fp32 w5"},
+    {k_render_pw<32, 8, 1, 256, 4, false>, 256, 1, "pw K32 L8 q16 w4"},
+    {k_render_pw<32, 8, 1, 256, 5, false>, 256, 1, "pw K32 L8 q16 w5"},
+    {k_render_pw<32, 8, 2, 1024, 4, false>, 1024, 2, "pw K32 L8 q16-LDS 1024t w4"},
+    {k_render_pw<32, 8, 2, 512, 5, false>, 512, 2, "pw K32 L8 q16-LDS 512t w5"},
+    {k_render_pw<32, 8, 2, 512, 6, false>, 512, 2, "pw K32 L8 q16-LDS 512t w6"},
+};
+int render_variant_count() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
+const char* render_variant_name(int v) { return (v >= 0 && v < render_variant_count()) ? kVariants[v].name : "?"; }
+int render_variant_threads(int v) { return (v >= 0 && v < render_variant_count()) ? kVariants[v].threads : 0; }
+
+static size_t variant_lds(const VariantDesc& d, uint32_t stack_entries, uint32_t n_nodes)
 {
-    const size_t lds = (size_t)(kRenderThreads / 64) * stack_entries * 256u;
-    hipError_t e = hipFuncSetAttribute((const void*)k_render, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, (const void*)k_render, kRenderThreads, lds);
+    size_t lds = (size_t)(d.threads / 64) * stack_entries * 256u;
+    if (d.node_fmt == 2) lds += (size_t)n_nodes * sizeof(QNode);
+    return lds;
 }
 
-hipError_t launch_render(const RenderArgs& args, uint32_t grid_blocks, hipStream_t stream)
+hipError_t render_occupancy(int variant, uint32_t stack_entries, uint32_t n_nodes, int* blocks_per_cu)
 {
-    const size_t lds = (size_t)(kRenderThreads / 64) * args.stack_entries * 256u;
-    k_render<<<grid_blocks, kRenderThreads, lds, stream>>>(args);
+    if (variant < 0 || variant >= render_variant_count()) return hipErrorInvalidValue;
+    const VariantDesc& d = kVariants[variant];
+    const size_t lds = variant_lds(d, stack_entries, n_nodes);
+    *blocks_per_cu = 0;
+    if (lds > 160u * 1024u) return hipSuccess;      // does not fit: 0 blocks, caller reports it
+    hipError_t e = hipFuncSetAttribute((const void*)d.k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, (const void*)d.k, d.threads, lds);
+}
+
+hipError_t launch_render(int variant, const RenderArgs& args, uint32_t grid_blocks, hipStream_t stream)
+{
+    if (variant < 0 || variant >= render_variant_count()) return hipErrorInvalidValue;
+    const VariantDesc& d = kVariants[variant];
+    const size_t lds = variant_lds(d, args.stack_entries, args.n_lds_nodes);
+    hipLaunchKernelGGL(d.k, dim3(grid_blocks), dim3(d.threads), lds, stream, args);
     return hipGetLastError();
 }
 

@@ -51,8 +51,9 @@ def parse():
     ap.add_argument("--spp", type=int, default=SPP_PER_LAUNCH)
     ap.add_argument("--max-depth", type=int, default=MAX_DEPTH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=4)
+    ap.add_argument("--cpu-spp", type=int, default=8)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=-1, help="render kernel variant (-1 = library default)")
     ap.add_argument("--save", default="", help="write the final framebuffer as PPM (rank 0)")
     return ap.parse_args()
 
@@ -71,6 +72,7 @@ def cpu_baseline(pt, obj, params, cpu_spp):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))      # the GPU box's CPU share for one GPU
     _, _, st, secs = sc.render(q, use_bvh=True, threads=cores)
     rays = st["radiance_rays"] + st["shadow_rays"]
     sc.close()
@@ -115,8 +117,8 @@ def main():
     state.params = p
     assert L.pt_set_partition(state.context, rank, world) == 0
     assert L.pt_set_stream(state.context, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
-    if a.blocks_per_cu:
-        assert L.pt_set_tuning(state.context, a.blocks_per_cu, 0) == 0
+    if a.blocks_per_cu or a.variant >= 0:
+        assert L.pt_set_tuning(state.context, a.blocks_per_cu, max(a.variant, 0)) == 0
     info = pt.getBvhInfo(state)
 
     def step(frame):

@@ -94,7 +94,12 @@ typedef struct pt_stats {
     float    kernel_ms;       /* megakernel duration, HIP events on its stream*/
     float    launch_ms;       /* pt_launch entry -> synchronised return       */
     uint32_t pixels;          /* pixels this launch rendered (tile partition) */
-    uint32_t reserved;
+    uint32_t grid_blocks;     /* persistent workgroups launched                */
+    /* scheduler diagnostics (0 for the segment-synchronous variant):          */
+    uint64_t trav_wave_steps;   /* BVH loop iterations summed over waves       */
+    uint64_t trav_lane_steps;   /* ... times lanes with a ray in flight        */
+    uint64_t shade_wave_rounds; /* shade/regenerate rounds summed over waves   */
+    uint64_t shade_lane_rounds; /* ... times lanes shaded in them              */
 } pt_stats;
 
 /* What the on-device LBVH build produced. */
@@ -156,8 +161,10 @@ int pt_set_partition(pt_ctx* ctx, int rank, int world);
  * a float4 DEVICE array and writes uchar4 into frameBuffer (device or mapped host).          */
 int pt_resolve_framebuffer(pt_ctx* ctx, const float* accumulation_rgba, uint8_t* framebuffer_rgba, size_t n_pixels);
 
-/* Launch geometry override (0 = automatic): persistent workgroups per CU. */
-int pt_set_tuning(pt_ctx* ctx, int blocks_per_cu, int reserved);
+/* Launch tuning: persistent workgroups per CU (0 = from the occupancy query) and the render
+ * kernel variant (0 = segment-synchronous, n >= 1 = persistent traversal with deferred shading,
+ * see csrc/render_megakernel.hip).  Every variant produces the same image bits.           */
+int pt_set_tuning(pt_ctx* ctx, int blocks_per_cu, int variant);
 
 /* Stream the launches are enqueued on (a hipStream_t, e.g. torch's current
  * stream); NULL restores the context's own stream (PathTracerMain.cpp:161). */
