@@ -1,0 +1,72 @@
+"""The C-ABI library: it loads, exports every symbol include/acgpt.h declares, its POD layouts match
+the reference's, and without a GPU it FAILS LOUDLY instead of falling back to anything."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+from acgpathtracing_amd import _build, _native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _build.build_hip()
+    return _native.hip()
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "acgpt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pt_[a-z_]+)\s*\(", text)))
+
+
+def test_exports_every_declared_symbol(lib):
+    syms = header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), "libacgpt_hip.so does not export %s" % s
+    assert sorted(_native.ABI_SYMBOLS) == syms, "the Python binding and the header disagree"
+    out = subprocess.run(["nm", "-D", "--defined-only", _native.hip_library_path()], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (pt_[a-z_]+)", out))
+    assert exported == set(syms)
+    assert lib.pt_abi_version() == 1
+
+
+def test_pod_layouts_match_the_reference():
+    assert C.sizeof(_native.PathTraceParams) == 168          # pathTracer.h:85-108 on LP64
+    assert _native.PathTraceParams.accumulationBuffer.offset == 8
+    assert _native.PathTraceParams.frameBuffer.offset == 16
+    assert _native.PathTraceParams.width.offset == 24
+    assert _native.PathTraceParams.cameraEye.offset == 40
+    assert _native.PathTraceParams.areaLight.offset == 88
+    assert _native.PathTraceParams.handle.offset == 152
+    assert _native.PathTraceParams.useDirectLighting.offset == 160
+    assert _native.PathTraceParams.useImportanceSampling.offset == 161
+    assert C.sizeof(_native.Material) == 40 and _native.Material.bsdfType.offset == 36     # TinyObjWrapper.h:33-40
+    assert C.sizeof(_native.AreaLight) == 60
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful on a machine without a GPU")
+def test_no_gpu_means_loud_failure(lib):
+    ctx = C.c_void_p()
+    assert lib.pt_create(C.byref(ctx), 0) != 0
+    assert not ctx.value
+    assert b"no HIP device" in lib.pt_last_error(None)
+    import acgpathtracing_amd as pt
+    with pytest.raises(pt.PathTracerError):
+        pt.createDeviceContext(pt.PathTracerState())
+
+
+def test_product_does_not_import_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/."""
+    pkg = os.path.join(ROOT, "acgpathtracing_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle_lib" not in text and "liboracle" not in text and "oracle/" not in text.replace("oracle/oracle_pt.cpp", "").replace("oracle/_ref", "").replace("oracle/Makefile", ""), f
