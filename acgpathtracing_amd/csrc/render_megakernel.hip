@@ -201,7 +201,9 @@ k_render(const RenderArgs A)
 //           1 = 16-bit grid boxes, 32-byte nodes in global memory (2 loads per visit)
 //           2 = the same 32-byte nodes staged into LDS by each workgroup (scenes whose node array
 //               fits beside the lane stacks; 1024-thread workgroups so one copy serves 16 waves)
-template <int SHADE_K, int LEAF_K, int NODE_FMT, int THREADS, int MINW, bool STATS>
+// DIAG (timing experiments only, never a product variant): 1 = 12 extra dependent VALU per inner
+// step, 2 = two extra 16-byte loads per inner step.
+template <int SHADE_K, int LEAF_K, int NODE_FMT, int THREADS, int MINW, bool STATS, int DIAG = 0>
 __global__ void __launch_bounds__(THREADS, MINW)
 k_render_pw(const RenderArgs A)
 {
@@ -367,6 +369,20 @@ k_render_pw(const RenderArgs A)
                     n1 = fmaxf(fmaxf(fminf(u0, u1), fminf(v0, v1)), fmaxf(fminf(w0, w1), rtmin));
                     f1 = fminf(fminf(fmaxf(u0, u1), fmaxf(v0, v1)), fmaxf(w0, w1)) * kFarWiden;
                 }
+                if (DIAG == 1) {
+                    float d = n0;
+#pragma unroll
+                    for (int k = 0; k < 12; k++) asm volatile("v_add_f32 %0, %0, %1" : "+v"(d) : "v"(f0));
+                    asm volatile("" :: "v"(d));
+                }
+                if (DIAG == 2) {
+                    const float4* xp = (const float4*)(sc.nodes + node);
+    typedef float v4f __attribute__((ext_vector_type(4)));
+                    v4f e0, e1;
+                    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:32\n\ts_waitcnt vmcnt(0)"
+                                 : "=&v"(e0), "=&v"(e1) : "v"(xp) : "memory");
+                    asm volatile("" :: "v"(e0), "v"(e1));
+                }
                 f0 = fminf(f0, best_t);
                 f1 = fminf(f1, best_t);
                 const bool h0 = n0 <= f0, h1 = n1 <= f1;
@@ -477,6 +493,8 @@ static const VariantDesc kVariants[] = {
     {k_render_pw<32, 8, 2, 1024, 4, false>, 1024, 2, "pw K32 L8 q16-LDS 1024t w4"},
     {k_render_pw<32, 8, 2, 512, 5, false>, 512, 2, "pw K32 L8 q16-LDS 512t w5"},
     {k_render_pw<32, 8, 2, 512, 6, false>, 512, 2, "pw K32 L8 q16-LDS 512t w6"},
+    {k_render_pw<32, 8, 0, 256, 4, false, 1>, 256, 0, "DIAG pw K32 L8 fp32 w4 +12 VALU/step"},
+    {k_render_pw<32, 8, 0, 256, 4, false, 2>, 256, 0, "DIAG pw K32 L8 fp32 w4 +2 loads/step"},
 };
 int render_variant_count() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
 const char* render_variant_name(int v) { return (v >= 0 && v < render_variant_count()) ? kVariants[v].name : "?"; }

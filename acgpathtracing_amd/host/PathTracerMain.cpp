@@ -1,0 +1,236 @@
+// PathTracerMain.cpp — headless counterpart of the reference's PathTracer_Optix/PathTracerMain.cpp.
+//
+// Same structure, same function names over a PathTracerState, same defaults (512x512, 128 samples
+// per launch, maxDepth 4, both toggles off, the hard-coded area light and camera); what the
+// reference hard-codes or reads from the keyboard is a command line here, and frames go to image
+// files instead of a GLFW window:
+//
+//   acgpt_main --obj scene.obj [--width 512 --height 512] [--spp-per-launch 128] [--frames 8]
+//              [--max-depth 4] [--direct-lighting] [--importance-sampling] [--device 0]
+//              [--keys "0,1,UP,UP,R"] [--out frame.png] [--dump-every k] [--zero-copy]
+//
+// --keys replays the reference's key handler (PathTracerMain.cpp:100-141) between frames, one key
+// per frame: 0 = direct lighting, 1 = importance sampling, UP/DOWN = max depth +-1 in [1,28],
+// R = reset, Q = quit; every change resets the accumulation and the frame index.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/acgpt.h"
+#include "Camera.h"
+#include "Exception.h"
+#include "ImageIO.h"
+#include "OutputBuffer.h"
+#include "TinyObjWrapper.h"
+#include "Trackball.h"
+
+using namespace acgpt;
+
+constexpr unsigned int maxiumumRecursionDepth = 28;     // PathTracerMain.cpp:42
+static int32_t samples_per_launch = 128;                // :43
+static uint32_t frame_counter = 0, sample_summ = 0;
+static double avg_ms = 0.0, total_ms = 0.0;
+static bool refreshAccumulationBuffer = false;
+static Camera g_camera;
+
+struct PathTracerState {                                // :71-93
+    pt_ctx* context = nullptr;
+    pt_params params = {};
+    int device = 0;
+};
+
+static bool keyCallback(PathTracerState& state, const std::string& key)   // :100-141; false = quit
+{
+    pt_params* params = &state.params;
+    if (key == "Q" || key == "ESC") return false;
+    if (key == "0") {
+        params->useDirectLighting = !params->useDirectLighting;
+        std::cout << std::endl << "Using Direct Lighting: " << (params->useDirectLighting ? "yes" : "no") << std::endl;
+        refreshAccumulationBuffer = true;
+    } else if (key == "1") {
+        params->useImportanceSampling = !params->useImportanceSampling;
+        std::cout << std::endl << "Using Importance Sampling: " << (params->useImportanceSampling ? "yes" : "no") << std::endl;
+        refreshAccumulationBuffer = true;
+    } else if (key == "UP") {
+        params->maxDepth = std::min((int)maxiumumRecursionDepth, (int)params->maxDepth + 1);
+        refreshAccumulationBuffer = true;
+        std::cout << std::endl << "Max Depth: " << params->maxDepth << std::endl;
+    } else if (key == "DOWN") {
+        params->maxDepth = std::max(1, (int)params->maxDepth - 1);
+        refreshAccumulationBuffer = true;
+        std::cout << std::endl << "Max Depth: " << params->maxDepth << std::endl;
+    } else if (key == "R") {
+        refreshAccumulationBuffer = true;
+    }
+    return true;
+}
+
+static void allocAccumulation(PathTracerState& state)
+{
+    void* p = nullptr;
+    PT_CHECK(state.context, pt_device_malloc(state.context, &p, (size_t)state.params.width * state.params.height * 4 * sizeof(float)));
+    state.params.accumulationBuffer = (float*)p;
+}
+
+static void initializeTheLaunch(PathTracerState& state)                   // :143-164
+{
+    allocAccumulation(state);
+    state.params.frameBuffer = nullptr;
+    state.params.samplesPerPixel = samples_per_launch;
+    state.params.currentFrameIdx = 0u;
+    pt_area_light& al = state.params.areaLight;
+    al.emission = {10.0f, 10.0f, 10.0f};
+    al.corner = {343.0f, 547.0f, 227.0f};
+    al.v1 = {0.0f, 0.0f, 105.0f};
+    al.v2 = {-130.0f, 0.0f, 0.0f};
+    const float3 n = normalize(cross(make_float3(al.v1.x, al.v1.y, al.v1.z), make_float3(al.v2.x, al.v2.y, al.v2.z)));
+    al.normal = {n.x, n.y, n.z};
+    state.params.handle = pt_scene_handle(state.context);
+}
+
+static void updateState(OutputBuffer<uchar4>&, PathTracerState& state)    // :166-182
+{
+    if (refreshAccumulationBuffer) {
+        refreshAccumulationBuffer = false;
+        state.params.currentFrameIdx = 0;
+        sample_summ = 0; frame_counter = 0; avg_ms = 0; total_ms = 0;
+        PT_CHECK(state.context, pt_device_free(state.context, state.params.accumulationBuffer));
+        allocAccumulation(state);
+    }
+}
+
+static void LaunchCurrentFrame(OutputBuffer<uchar4>& output_buffer, PathTracerState& state)   // :184-210
+{
+    uchar4* result_buffer_data = output_buffer.map();
+    state.params.frameBuffer = reinterpret_cast<uint8_t*>(result_buffer_data);
+    PT_CHECK(state.context, pt_launch(state.context, &state.params));
+    output_buffer.unmap();
+}
+
+static void initCamera()                                                 // :228-233
+{
+    g_camera.setEye(make_float3(278.0f, 273.0f, -900.0f));
+    g_camera.setLookat(make_float3(278.0f, 273.0f, 330.0f));
+    g_camera.setUp(make_float3(0.0f, 1.0f, 0.0f));
+    g_camera.setFovY(35.0f);
+}
+
+static void createDeviceContext(PathTracerState& state)                  // :240-258
+{
+    if (pt_create(&state.context, state.device) != 0) throw Exception(std::string("createDeviceContext: ") + pt_last_error(nullptr));
+}
+
+static void buildTheAccelarationStructure(PathTracerState& state, const TinyObjWrapper& objs)   // :260-398 (+ :544-627)
+{
+    std::vector<float> h_vertices = objs.getVerticesFloat();
+    std::vector<uint32_t> h_mat_indices = objs.getMaterialIndices();
+    std::vector<uint32_t> h_indxbuffer = objs.getIndexBuffer();
+    std::vector<Material> materials = objs.getMaterials();
+    PT_CHECK(state.context, pt_set_scene(state.context, h_vertices.data(), h_vertices.size() / 4, h_indxbuffer.data(), h_indxbuffer.size() / 3,
+                                         h_mat_indices.data(), reinterpret_cast<const pt_material*>(materials.data()), materials.size()));
+}
+
+static void CleanAllTheThings(PathTracerState& state)                    // :629-646
+{
+    if (state.params.accumulationBuffer) pt_device_free(state.context, state.params.accumulationBuffer);
+    pt_destroy(state.context);
+    state.context = nullptr;
+}
+
+int main(int argc, char** argv)
+{
+    std::string objfilepath, out = "frame.png", keys;
+    int32_t width = 512, height = 512, frames = 8, dump_every = 0;
+    bool zero_copy = false;
+    PathTracerState state;
+    state.params.useDirectLighting = false;
+    state.params.useImportanceSampling = false;
+    state.params.maxDepth = 4;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        auto next = [&]() -> const char* { if (i + 1 >= argc) { std::cerr << "missing value for " << a << std::endl; exit(2); } return argv[++i]; };
+        if (a == "--obj") objfilepath = next();
+        else if (a == "--width") width = atoi(next());
+        else if (a == "--height") height = atoi(next());
+        else if (a == "--spp-per-launch") samples_per_launch = atoi(next());
+        else if (a == "--frames") frames = atoi(next());
+        else if (a == "--max-depth") state.params.maxDepth = (uint32_t)std::min((int)maxiumumRecursionDepth, std::max(1, atoi(next())));
+        else if (a == "--direct-lighting") state.params.useDirectLighting = true;
+        else if (a == "--importance-sampling") state.params.useImportanceSampling = true;
+        else if (a == "--device") state.device = atoi(next());
+        else if (a == "--keys") keys = next();
+        else if (a == "--out") out = next();
+        else if (a == "--dump-every") dump_every = atoi(next());
+        else if (a == "--zero-copy") zero_copy = true;
+        else { std::cerr << "unknown option " << a << std::endl; return 2; }
+    }
+    if (objfilepath.empty()) { std::cerr << "usage: acgpt_main --obj scene.obj [options]" << std::endl; return 2; }
+    std::vector<std::string> key_list;
+    { std::stringstream ss(keys); std::string k; while (std::getline(ss, k, ',')) if (!k.empty()) key_list.push_back(k); }
+
+    TinyObjWrapper obj(objfilepath);
+    if (!obj.loaded()) return 1;
+    state.params.width = width;
+    state.params.height = height;
+    try {
+        initCamera();
+        g_camera.setAspectRatio(static_cast<float>(state.params.width) / static_cast<float>(state.params.height));
+        const float3 eye = g_camera.eye();
+        state.params.cameraEye = {eye.x, eye.y, eye.z};
+        float3 U, V, W;
+        g_camera.UVWFrame(U, V, W);
+        state.params.cameraU = {U.x, U.y, U.z}; state.params.cameraV = {V.x, V.y, V.z}; state.params.cameraW = {W.x, W.y, W.z};
+
+        std::cout << "Using Direct Lighting: " << (state.params.useDirectLighting ? "yes" : "no") << std::endl;
+        std::cout << "Using Importance Sampling: " << (state.params.useImportanceSampling ? "yes" : "no") << std::endl;
+        createDeviceContext(state);
+        buildTheAccelarationStructure(state, obj);
+        std::cout << "Acceleration Structure Built" << std::endl;
+        initializeTheLaunch(state);
+        std::cout << "Launch Initialized" << std::endl;
+        uint64_t rays = 0;
+        {
+            OutputBuffer<uchar4> output_buffer(state.context, zero_copy ? OutputBufferType::ZERO_COPY : OutputBufferType::DEVICE,
+                                               state.params.width, state.params.height);
+            size_t next_key = 0;
+            for (int f = 0; f < frames; f++) {
+                auto start = std::chrono::high_resolution_clock::now();
+                if (next_key < key_list.size() && f > 0) { if (!keyCallback(state, key_list[next_key++])) break; }
+                updateState(output_buffer, state);
+                LaunchCurrentFrame(output_buffer, state);
+                ++state.params.currentFrameIdx;
+                auto end = std::chrono::high_resolution_clock::now();
+                const double ms = std::chrono::duration<double, std::milli>(end - start).count();
+                avg_ms += ms; total_ms += ms;
+                sample_summ += samples_per_launch;
+                frame_counter++;
+                pt_stats st; pt_get_stats(state.context, &st);
+                rays += st.radiance_rays + st.shadow_rays;
+                std::cout << "\rFrame Render Time: " << (long)ms << "ms" << std::flush;
+                if (dump_every > 0 && (f + 1) % dump_every == 0 && f + 1 < frames) {
+                    std::stringstream nm; nm << out << "." << (f + 1) << ".ppm";
+                    saveImage(nm.str(), reinterpret_cast<const uint8_t*>(output_buffer.getHostPointer()), width, height);
+                }
+            }
+            std::cout << std::endl;
+            if (!saveImage(out, reinterpret_cast<const uint8_t*>(output_buffer.getHostPointer()), width, height))
+                std::cerr << "could not write " << out << std::endl;
+        }
+        CleanAllTheThings(state);
+        if (frame_counter > 0) avg_ms /= frame_counter;
+        std::cout << "Total Samples " << sample_summ << std::endl;
+        std::cout << "Average ms per frame: " << (long)avg_ms << std::endl;
+        std::cout << "Total ms: " << (long)total_ms << std::endl;
+        std::cout << "Rays: " << rays << "  Mray/s: " << (total_ms > 0 ? rays / total_ms / 1e3 : 0.0) << std::endl;
+    } catch (const std::exception& e) {
+        std::cerr << "Caught exception: " << e.what() << std::endl;
+        return 1;
+    }
+    return 0;
+}

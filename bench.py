@@ -95,9 +95,14 @@ def main():
         raise SystemExit("N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # Rehearsal on a one-GPU box (never used by the driver): every rank shares cuda:0 and the
+    # reduce goes through gloo on host copies.  Exercises partition + reduce + resolve end to end.
+    rehearse = os.environ.get("ACGPT_REHEARSE_SAME_GPU") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    D.init_process_group("nccl" if world > 1 else None)
+    D.init_process_group(("gloo" if rehearse else "nccl") if world > 1 else None)
     L = _native.hip()
 
     # ---- scene + context (outside the timed region: inputs resident in HBM) ------------------
@@ -142,13 +147,19 @@ def main():
         rays += int(s.radiance_rays); shadow += int(s.shadow_rays); paths += int(s.paths)
         kernel_ms.append(float(s.kernel_ms))
     if world > 1:
-        D.reduce_accumulation(accum, dst=0)
+        if rehearse:
+            host = accum.cpu()
+            D.reduce_accumulation(host, dst=0)
+            accum.copy_(host)
+        else:
+            D.reduce_accumulation(accum, dst=0)
         if rank == 0:
             assert L.pt_resolve_framebuffer(state.context, C.c_void_p(accum.data_ptr()), C.c_void_p(fb.data_ptr()), a.width * a.height) == 0
     torch.cuda.synchronize(); D.barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = D.max_over_ranks(elapsed, dev if world > 1 else None)
-    tot_rays, tot_shadow, tot_paths = D.sum_over_ranks([rays, shadow, paths], dev if world > 1 else None)
+    cdev = dev if (world > 1 and not rehearse) else None
+    elapsed = D.max_over_ranks(elapsed, cdev)
+    tot_rays, tot_shadow, tot_paths = D.sum_over_ranks([rays, shadow, paths], cdev)
 
     # ---- report ---------------------------------------------------------------------------------------
     if rank == 0:
