@@ -62,7 +62,7 @@ assert C.sizeof(AreaLight) == 60
 
 # every symbol include/acgpt.h declares
 ABI_SYMBOLS = [
-    "pt_create", "pt_destroy", "pt_last_error", "pt_set_scene", "pt_scene_handle", "pt_get_bvh_info",
+    "pt_create", "pt_destroy", "pt_last_error", "pt_set_scene", "pt_set_build_mode", "pt_scene_handle", "pt_get_bvh_info",
     "pt_launch", "pt_resolve_framebuffer", "pt_set_partition", "pt_set_tuning", "pt_set_stream", "pt_get_stats",
     "pt_trace_closest", "pt_trace_any", "pt_read_morton",
     "pt_device_malloc", "pt_device_free", "pt_device_memset", "pt_copy_to_host", "pt_copy_to_device",
@@ -95,6 +95,7 @@ def hip():
     L.pt_destroy.argtypes = [vp]; L.pt_destroy.restype = None
     L.pt_last_error.argtypes = [vp]; L.pt_last_error.restype = C.c_char_p
     L.pt_set_scene.argtypes = [vp, vp, sz, vp, sz, vp, vp, sz]; L.pt_set_scene.restype = C.c_int
+    L.pt_set_build_mode.argtypes = [vp, C.c_int]; L.pt_set_build_mode.restype = C.c_int
     L.pt_scene_handle.argtypes = [vp]; L.pt_scene_handle.restype = C.c_uint64
     L.pt_get_bvh_info.argtypes = [vp, C.POINTER(BvhInfo)]; L.pt_get_bvh_info.restype = C.c_int
     L.pt_launch.argtypes = [vp, C.POINTER(PathTraceParams)]; L.pt_launch.restype = C.c_int

@@ -32,6 +32,7 @@ struct pt_ctx {
     uint32_t stack_entries = 8;
     int blocks_per_cu = 0;        // from the occupancy query for the current stack size
     int tune_blocks_per_cu = 0;   // user override
+    int build_mode = 1;           // 0 Karras LBVH, 1 PLOC over the Morton order
     int variant = ptd::kDefaultVariant;   // render kernel variant (render_megakernel.hip)
     uint32_t* d_queue = nullptr;              // 8 shard heads
     unsigned long long* d_counters = nullptr; // 8 counters
@@ -125,7 +126,7 @@ PT_API int pt_set_scene(pt_ctx* c, const float* verts_xyzw, size_t n_verts, cons
     CK(c, hipStreamSynchronize(c->stream));
     free_scene(c);
     std::string err;
-    if (!ptd::build_lbvh(verts_xyzw, n_verts, idx, n_tris, mat_ids, c->stream, c->bvh, err)) return fail(c, "pt_set_scene: " + err);
+    if (!ptd::build_lbvh(verts_xyzw, n_verts, idx, n_tris, mat_ids, c->build_mode, c->stream, c->bvh, err)) return fail(c, "pt_set_scene: " + err);
     if (n_mats) {
         CK(c, hipMalloc((void**)&c->d_mats, n_mats * sizeof(pt_material)));
         CK(c, hipMemcpy(c->d_mats, mats, n_mats * sizeof(pt_material), hipMemcpyHostToDevice));
@@ -178,6 +179,14 @@ PT_API int pt_set_tuning(pt_ctx* c, int blocks_per_cu, int variant)
     c->variant = variant;
     CK(c, ptd::render_occupancy(c->variant, c->stack_entries, c->bvh.n_nodes, &c->blocks_per_cu));
     if (c->blocks_per_cu < 1) return fail(c, "pt_set_tuning: this kernel variant does not fit the current scene in LDS");
+    return 0;
+}
+
+PT_API int pt_set_build_mode(pt_ctx* c, int mode)
+{
+    if (!c) return fail(nullptr, "pt_set_build_mode: null context");
+    if (mode != 0 && mode != 1) return fail(c, "pt_set_build_mode: 0 = Karras LBVH, 1 = PLOC");
+    c->build_mode = mode;
     return 0;
 }
 

@@ -18,11 +18,14 @@ struct LbvhResult {
     uint32_t   n_tris = 0, n_nodes = 0, max_depth = 0;
     float      scene_lo[3] = {0, 0, 0}, scene_hi[3] = {0, 0, 0};
     float      build_ms = 0.0f;
+    int        mode = 0;               // 0 Karras radix tree, 1 PLOC
+    uint32_t   build_iterations = 0;   // PLOC merge rounds
 };
 
 // Host arrays in, device BVH out.  Synchronous on return.  false + err on failure.
+// mode 0: Karras radix tree over the sorted Morton codes; mode 1: PLOC over the same order.
 bool build_lbvh(const float* h_verts_xyzw, size_t n_verts, const uint32_t* h_idx, size_t n_tris,
-                const uint32_t* h_mat_ids, hipStream_t stream, LbvhResult& out, std::string& err);
+                const uint32_t* h_mat_ids, int mode, hipStream_t stream, LbvhResult& out, std::string& err);
 
 void free_lbvh(LbvhResult& r);
 

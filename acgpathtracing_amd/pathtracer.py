@@ -376,7 +376,7 @@ def CleanAllTheThings(state):
 
 
 def setup(obj_path, width=512, height=512, max_depth=4, direct_lighting=False, importance_sampling=False,
-          spp=samples_per_launch, device_id=0):
+          spp=samples_per_launch, device_id=0, build_mode=None):
     """The body of main() up to the frame loop (PathTracerMain.cpp:650-684) as one call."""
     obj = TinyObjWrapper(obj_path)
     if not obj.dataLoaded:
@@ -392,6 +392,8 @@ def setup(obj_path, width=512, height=512, max_depth=4, direct_lighting=False, i
     U, V, W = cam.UVWFrame()
     state.params.cameraU, state.params.cameraV, state.params.cameraW = _f3(U), _f3(V), _f3(W)
     createDeviceContext(state, device_id)
+    if build_mode is not None:
+        _check(state.context, _native.hip().pt_set_build_mode(state.context, int(build_mode)), "pt_set_build_mode")
     buildTheAccelarationStructure(state, obj)
     createModule(state); createProgramGroups(state); createPipeline(state)
     createShaderBindingTable(state, obj)

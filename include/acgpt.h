@@ -137,6 +137,10 @@ int      pt_set_scene(pt_ctx* ctx,
                       const uint32_t* idx, size_t n_tris,
                       const uint32_t* mat_ids,
                       const pt_material* mats, size_t n_mats);
+/* Hierarchy builder used by the NEXT pt_set_scene: both start from the same on-device Morton radix
+ * sort; 0 = Karras radix tree (classic LBVH), 1 = PLOC (locally-ordered clustering; default, fewer
+ * node visits per ray).  Results of every query are identical, only speed differs.          */
+int      pt_set_build_mode(pt_ctx* ctx, int mode);
 uint64_t pt_scene_handle(pt_ctx* ctx);
 int      pt_get_bvh_info(pt_ctx* ctx, pt_bvh_info* out);
 

@@ -114,6 +114,28 @@ def test_trace_closest_bit_exact(full):
     assert (prim != 0xFFFFFFFF).mean() > 0.5
 
 
+def test_karras_tree_gives_the_same_answers(gpu_state_factory, oracle):
+    """Both hierarchy builders (Karras radix tree, PLOC) sit behind the same triangle test: identical hits."""
+    state, obj = gpu_state_factory(SCENE_FULL, width=64, height=64, build_mode=0)
+    sc = oracle.scene(obj.getVerticesFloat(), obj.getIndexBuffer(), obj.getMaterialIndices(), obj.getMaterials())
+    v, idx = scene_arrays(obj)
+    rays = np.concatenate([random_rays(60000, 31), adversarial_rays(v, idx, 32)])
+    n = rays.shape[0]
+    t = np.zeros(n, np.float32); prim = np.zeros(n, np.uint32); hit = np.zeros(n, np.uint8)
+    L = _native.hip()
+    assert L.pt_trace_closest(state.context, rays.ctypes.data, n, t.ctypes.data, prim.ctypes.data) == 0
+    assert L.pt_trace_any(state.context, rays.ctypes.data, n, hit.ctypes.data) == 0
+    t_ref, prim_ref = sc.trace_closest(rays, use_bvh=False)
+    assert np.array_equal(prim, prim_ref) and np.array_equal(t.view(np.uint32), t_ref.view(np.uint32))
+    assert np.array_equal(hit, sc.trace_any(rays, use_bvh=False))
+    info = pt.getBvhInfo(state)
+    assert info.n_nodes == idx.shape[0] - 1 and info.max_depth < info.stack_entries
+    p = make_params(96, 64, 4, 6, True, True)
+    acc, _, _ = _gpu_render(state, p)
+    ref, _, _, _ = sc.render(copy_params(p), use_bvh=True)
+    assert image_mse(acc, ref) < MSE_TOL
+
+
 def test_trace_any_bit_exact(full):
     state, obj, sc = full
     v, idx = scene_arrays(obj)

@@ -27,11 +27,12 @@ def main():
     ap.add_argument("--variants", default="all")
     ap.add_argument("--blocks-per-cu", default="0")
     ap.add_argument("--no-dl", action="store_true")
+    ap.add_argument("--build-mode", type=int, default=None, help="0 Karras LBVH, 1 PLOC (library default)")
     a = ap.parse_args()
     L = _native.hip()
     path = a.scene if os.path.isabs(a.scene) else os.path.join(pt.SCENES, a.scene)
     state, obj = pt.setup(path, width=a.width, height=a.height, max_depth=a.max_depth,
-                          direct_lighting=not a.no_dl, importance_sampling=True, spp=a.spp)
+                          direct_lighting=not a.no_dl, importance_sampling=True, spp=a.spp, build_mode=a.build_mode)
     p = make_params(a.width, a.height, a.spp, a.max_depth, not a.no_dl, True)
     keep_a, keep_h = state.params.accumulationBuffer, state.params.handle
     C.memmove(C.byref(state.params), C.byref(p), C.sizeof(p))
