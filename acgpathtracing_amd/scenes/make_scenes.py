@@ -171,7 +171,7 @@ def mtl(glass_name, metal_name):
             "newmtl %s\nKd 0.8 0.5 0.9\nPr 0.2\nPm 1.0\n" % metal_name)
 
 
-def stress_scene(path_obj, n_spheres=64, subdiv=5, seed=0x9E3779B9):
+def stress_scene(path_obj, n_spheres=64, subdiv=5, seed=0x9E3779B9, mtl_name="stress_scene.mtl"):
     """Seeded ~1.3 M-triangle scene inside the Cornell shell: n_spheres icospheres of
     20*4^subdiv triangles each (64 x 20480 = 1 310 720).  Positions from an LCG
     (cuda/random.h constants) with a fixed seed.  Writes path_obj and a sibling .mtl."""
@@ -182,8 +182,7 @@ def stress_scene(path_obj, n_spheres=64, subdiv=5, seed=0x9E3779B9):
         state = (1664525 * state + 1013904223) & 0xFFFFFFFF
         return (state & 0xFFFFFF) / 16777216.0
 
-    base = os.path.splitext(os.path.basename(path_obj))[0]
-    w = ObjWriter(base + ".mtl")
+    w = ObjWriter(mtl_name)
     w.quad("floor", "white", [(552.8, 0, 0), (0, 0, 0), (0, 0, 559.2), (549.6, 0, 559.2)])
     w.quad("ceiling", "white", [(556, 548.8, 0), (556, 548.8, 559.2), (0, 548.8, 559.2), (0, 548.8, 0)])
     w.quad("back", "white", [(549.6, 0, 559.2), (0, 0, 559.2), (0, 548.8, 559.2), (556, 548.8, 559.2)])
@@ -198,7 +197,7 @@ def stress_scene(path_obj, n_spheres=64, subdiv=5, seed=0x9E3779B9):
         w.mesh("s%03d" % k, mats[k % 3], sv * r + c, sf)
     with open(path_obj, "w") as fh:
         fh.write(w.text())
-    with open(os.path.join(os.path.dirname(path_obj), base + ".mtl"), "w") as fh:
+    with open(os.path.join(os.path.dirname(os.path.abspath(path_obj)), mtl_name), "w") as fh:
         fh.write("# stress scene materials\n" + MTL_COMMON)
 
 

@@ -303,3 +303,45 @@ def test_edge_cases(gpu_state_factory, oracle, tmp_path):
     mats = (pt.Material * 1)()
     assert L.pt_set_scene(state.context, vv.ctypes.data, 3, ii.ctypes.data, 1, mm.ctypes.data, C.addressof(mats), 1) != 0
     assert b"material index" in L.pt_last_error(state.context)
+
+
+def test_large_scene_properties(gpu_state_factory, oracle, tmp_path):
+    """BASELINE config-5 size (1.3 M triangles, generated from a fixed seed): brute force is out of
+    reach, so parity is checked (a) against brute force on a small ray sample, (b) against the
+    oracle's own BVH on a large one, (c) through size-independent properties: any-hit == (closest
+    hit exists) on the same interval, determinism across both hierarchy builders."""
+    import sys
+    sys.path.insert(0, pt.SCENES)
+    import make_scenes
+    path = str(tmp_path / "stress.obj")
+    make_scenes.stress_scene(path)
+    state, obj = gpu_state_factory(path, width=64, height=64)
+    L = _native.hip()
+    info = pt.getBvhInfo(state)
+    assert info.n_tris == 64 * 20480 + 12 and info.n_nodes == info.n_tris - 1
+    assert info.max_depth < info.stack_entries <= 128
+    sc = oracle.scene(obj.getVerticesFloat(), obj.getIndexBuffer(), obj.getMaterialIndices(), obj.getMaterials())
+    rays = random_rays(120000, 41, lo=(20, 20, 20), hi=(530, 530, 540))
+    n = rays.shape[0]
+    t = np.zeros(n, np.float32); prim = np.zeros(n, np.uint32); hit = np.zeros(n, np.uint8)
+    assert L.pt_trace_closest(state.context, rays.ctypes.data, n, t.ctypes.data, prim.ctypes.data) == 0
+    assert L.pt_trace_any(state.context, rays.ctypes.data, n, hit.ctypes.data) == 0
+    t_ref, p_ref = sc.trace_closest(rays, use_bvh=True)
+    assert np.array_equal(prim, p_ref) and np.array_equal(t.view(np.uint32), t_ref.view(np.uint32))
+    assert np.array_equal(hit != 0, prim != 0xFFFFFFFF)                       # (c) any-hit <=> a closest hit exists
+    tb, pb = sc.trace_closest(rays[:150], use_bvh=False)                       # (a) brute force sample
+    assert np.array_equal(prim[:150], pb) and np.array_equal(t[:150].view(np.uint32), tb.view(np.uint32))
+    # the other builder, same answers
+    assert L.pt_set_build_mode(state.context, 0) == 0
+    pt.buildTheAccelarationStructure(state, obj)
+    t2 = np.zeros(n, np.float32); prim2 = np.zeros(n, np.uint32)
+    assert L.pt_trace_closest(state.context, rays.ctypes.data, n, t2.ctypes.data, prim2.ctypes.data) == 0
+    assert np.array_equal(prim2, prim) and np.array_equal(t2.view(np.uint32), t.view(np.uint32))
+    assert L.pt_set_build_mode(state.context, 1) == 0
+    pt.buildTheAccelarationStructure(state, obj)
+    # a small render against the oracle
+    p = make_params(96, 54, 2, 4, True, True)
+    acc, _, st = _gpu_render(state, p)
+    ref, _, ref_st, _ = sc.render(copy_params(p), use_bvh=True)
+    assert image_mse(acc, ref) < MSE_TOL
+    assert abs(int(st[0].radiance_rays) - ref_st["radiance_rays"]) <= 5e-3 * ref_st["radiance_rays"]
