@@ -485,14 +485,14 @@ static const VariantDesc kVariants[] = {
     {k_render_pw<32, 8, 0, 256, 4, true>, 256, 0, "pw K32 L8 fp32 w4 stats"},
     {k_render_pw<32, 8, 0, 256, 4, false>, 256, 0, "pw K32 L8 fp32 w4"},
     {k_render_pw<32, 8, 0, 256, 5, false>, 256, 0, "pw K32 L8 fp32 w5"},
-    {k_render_pw<32, 8, 0, 256, 6, false>, 256, 0, "pw K32 L8 fp32 w6"},
-    {k_render_pw<32, 8, 0, 256, 8, false>, 256, 0, "pw K32 L8 fp32 w8"},
+    {k_render_pw<40, 4, 0, 256, 5, false>, 256, 0, "pw K40 L4 fp32 w5"},
+    {k_render_pw<40, 12, 0, 256, 5, false>, 256, 0, "pw K40 L12 fp32 w5"},
     {k_render_pw<40, 8, 0, 256, 5, false>, 256, 0, "pw K40 L8 fp32 w5"},
     {k_render_pw<32, 8, 1, 256, 4, false>, 256, 1, "pw K32 L8 q16 w4"},
-    {k_render_pw<32, 8, 1, 256, 5, false>, 256, 1, "pw K32 L8 q16 w5"},
+    {k_render_pw<48, 8, 0, 256, 5, false>, 256, 0, "pw K48 L8 fp32 w5"},
     {k_render_pw<32, 8, 2, 1024, 4, false>, 1024, 2, "pw K32 L8 q16-LDS 1024t w4"},
-    {k_render_pw<32, 8, 2, 512, 5, false>, 512, 2, "pw K32 L8 q16-LDS 512t w5"},
-    {k_render_pw<32, 8, 2, 512, 6, false>, 512, 2, "pw K32 L8 q16-LDS 512t w6"},
+    {k_render_pw<40, 16, 0, 256, 5, false>, 256, 0, "pw K40 L16 fp32 w5"},
+    {k_render_pw<36, 8, 0, 256, 5, false>, 256, 0, "pw K36 L8 fp32 w5"},
     {k_render_pw<32, 8, 0, 256, 4, false, 1>, 256, 0, "DIAG pw K32 L8 fp32 w4 +12 VALU/step"},
     {k_render_pw<32, 8, 0, 256, 4, false, 2>, 256, 0, "DIAG pw K32 L8 fp32 w4 +2 loads/step"},
 };
