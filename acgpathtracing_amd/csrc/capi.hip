@@ -25,7 +25,7 @@ struct pt_ctx {
     int n_cus = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // bracket the render kernel alone (k_items / k_finalize sit outside)
     ptd::LbvhResult bvh;
     pt_material* d_mats = nullptr;
     uint32_t n_mats = 0;
@@ -37,6 +37,9 @@ struct pt_ctx {
     uint32_t* d_queue = nullptr;              // 8 shard heads
     unsigned long long* d_counters = nullptr; // 8 counters
     int rank = 0, world = 1;
+    int chunks = 0;                           // sample chunks per pixel: 0 = automatic, else 1/2/4/8/16
+    float4* d_partial = nullptr; size_t partial_bytes = 0;
+    uint2* d_items = nullptr; size_t items_bytes = 0;
     pt_stats stats;
     uint64_t scene_serial = 0;
     std::string err;
@@ -104,6 +107,8 @@ PT_API void pt_destroy(pt_ctx* c)
     free_scene(c);
     if (c->d_queue) (void)hipFree(c->d_queue);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_partial) (void)hipFree(c->d_partial);
+    if (c->d_items) (void)hipFree(c->d_items);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -166,6 +171,14 @@ PT_API int pt_set_partition(pt_ctx* c, int rank, int world)
     if (!c) return fail(nullptr, "pt_set_partition: null context");
     if (world < 1 || rank < 0 || rank >= world) return fail(c, "pt_set_partition: need 0 <= rank < world");
     c->rank = rank; c->world = world;
+    return 0;
+}
+
+PT_API int pt_set_sample_chunks(pt_ctx* c, int chunks)
+{
+    if (!c) return fail(nullptr, "pt_set_sample_chunks: null context");
+    if (chunks != 0 && chunks != 1 && chunks != 2 && chunks != 4 && chunks != 8 && chunks != 16) return fail(c, "pt_set_sample_chunks: 0 (automatic), 1, 2, 4, 8 or 16");
+    c->chunks = chunks;
     return 0;
 }
 
@@ -237,8 +250,50 @@ PT_API int pt_launch(pt_ctx* c, const pt_params* p)
     a.useDL = p->useDirectLighting ? 1u : 0u;
     a.useIS = p->useImportanceSampling ? 1u : 0u;
     a.rank = c->rank; a.world = c->world;
-    a.total_samples = num_samples(c->world, p->width, p->height);
+    if (c->chunks > 0) {
+        if (p->samplesPerPixel % (uint32_t)c->chunks != 0u) return fail(c, "pt_launch: samplesPerPixel is not a multiple of the sample-chunk count");
+        while ((1 << a.chunk_shift) < c->chunks) a.chunk_shift++;
+    } else {
+        // automatic: 8 runs per pixel (16 when this rank holds few pixels), as long as every run keeps >= 4 samples
+        const uint32_t my_pixels = (uint32_t)(((uint64_t)p->width * p->height) / (uint64_t)c->world);
+        uint32_t want = my_pixels < (1u << 20) ? 4u : 3u;
+        while (want > 0u && (p->samplesPerPixel % (1u << want) != 0u || (p->samplesPerPixel >> want) < 4u)) want--;
+        a.chunk_shift = want;
+    }
+    // reserve per queue atomic: smaller while items are long (a parked reserve lengthens the tail of the
+    // launch), larger as the items get shorter and refills more frequent
+    static const uint32_t grant_by_shift[5] = {16u, 16u, 32u, 64u, 64u};
+    a.grant = grant_by_shift[a.chunk_shift];
+    a.chunk_spp = p->samplesPerPixel >> a.chunk_shift;
+    {   // LCG skip-ahead: chunk k starts 2 * k * chunk_spp draws after the pixel seed (two jitter draws per sample, :730)
+        uint32_t mul = 1u, add = 0u;
+        for (uint32_t k = 0; k < 16u; k++) {
+            a.lcg_mul[k] = mul; a.lcg_add[k] = add;
+            for (uint32_t i = 0; i < 2u * a.chunk_spp; i++) { add = 1664525u * add + 1013904223u; mul = 1664525u * mul; }
+        }
+    }
+    a.total_samples = num_samples(c->world, p->width, p->height) << a.chunk_shift;
     a.shard_size = ((a.total_samples + 7u) / 8u + 63u) & ~63u;
+    {
+        const size_t need = (size_t)a.total_samples * sizeof(uint2);
+        if (need > c->items_bytes) {
+            CK(c, hipStreamSynchronize(c->stream));
+            if (c->d_items) { (void)hipFree(c->d_items); c->d_items = nullptr; c->items_bytes = 0; }
+            CK(c, hipMalloc((void**)&c->d_items, need));
+            c->items_bytes = need;
+        }
+        a.items = c->d_items;
+    }
+    if (a.chunk_shift) {
+        const size_t need = ((size_t)p->width * p->height << a.chunk_shift) * sizeof(float4);
+        if (need > c->partial_bytes) {
+            CK(c, hipStreamSynchronize(c->stream));
+            if (c->d_partial) { (void)hipFree(c->d_partial); c->d_partial = nullptr; c->partial_bytes = 0; }
+            CK(c, hipMalloc((void**)&c->d_partial, need));
+            c->partial_bytes = need;
+        }
+        a.partial = c->d_partial;
+    }
     a.queue_heads = c->d_queue;
     a.counters = c->d_counters;
     a.stack_entries = c->stack_entries;
@@ -259,9 +314,11 @@ PT_API int pt_launch(pt_ctx* c, const pt_params* p)
 
     CK(c, hipMemsetAsync(c->d_queue, 0, 8 * sizeof(uint32_t), c->stream));
     CK(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
+    CK(c, ptd::launch_items(a, c->stream));
     CK(c, hipEventRecord(c->ev0, c->stream));
     CK(c, ptd::launch_render(c->variant, a, grid, c->stream));
     CK(c, hipEventRecord(c->ev1, c->stream));
+    if (a.chunk_shift) CK(c, ptd::launch_finalize(a, c->stream));
     unsigned long long h[8];
     CK(c, hipMemcpyAsync(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     CK(c, hipStreamSynchronize(c->stream));            // CUDA_SYNC_CHECK, PathTracerMain.cpp:209
@@ -270,7 +327,8 @@ PT_API int pt_launch(pt_ctx* c, const pt_params* p)
     c->stats.radiance_rays = h[0];
     c->stats.shadow_rays = h[1];
     c->stats.paths = h[2];
-    c->stats.pixels = (uint32_t)h[3];
+    c->stats.pixels = (uint32_t)(h[3] >> a.chunk_shift);
+    c->stats.sample_chunks = 1u << a.chunk_shift;
     c->stats.trav_wave_steps = h[4];
     c->stats.trav_lane_steps = h[5];
     c->stats.shade_wave_rounds = h[6];

@@ -17,12 +17,21 @@ struct RenderArgs {
     pt_area_light light;
     uint32_t  useDL, useIS;
     int       rank, world;
-    uint32_t  total_samples;   // StaticWorkDistribution::numSamples for `world`
+    uint32_t  total_samples;   // queue length: StaticWorkDistribution::numSamples(world) << chunk_shift
     uint32_t  shard_size;      // queue shard length (8 shards)
     uint32_t* queue_heads;     // 8 counters, zeroed before the launch
     unsigned long long* counters;   // [8] radiance rays, shadow rays, paths, pixels, traversal wave-steps, lane-steps, shade rounds, shade lanes
     uint32_t  stack_entries;
     uint32_t  n_lds_nodes;     // nodes staged into LDS (NODE_FMT 2), else 0
+    // sample chunks: a pixel's spp samples may be split into 2^chunk_shift consecutive runs, each run
+    // owned by its own lane (shortens the per-pixel serial chain when a GPU has few pixels).
+    uint32_t  chunk_shift;     // 0 = one lane per pixel (the reference's summation order)
+    uint32_t  chunk_spp;       // spp >> chunk_shift
+    uint32_t  lcg_mul[16];     // seed of chunk k = lcg_mul[k] * seed0 + lcg_add[k]  (2 * k * chunk_spp LCG steps)
+    uint32_t  lcg_add[16];
+    float4*   partial;         // [pixel][chunk] partial sums, used when chunk_shift > 0
+    uint32_t  grant;           // minimum work items taken per queue atomic (1 = exactly what is needed)
+    uint2*    items;           // [total_samples] work items of this launch: {px | py << 16, seed} (k_items)
 };
 
 int render_variant_count();
@@ -30,6 +39,8 @@ const char* render_variant_name(int variant);
 int render_variant_threads(int variant);
 hipError_t render_occupancy(int variant, uint32_t stack_entries, uint32_t n_nodes, int* blocks_per_cu);
 hipError_t launch_render(int variant, const RenderArgs& args, uint32_t grid_blocks, hipStream_t stream);
+hipError_t launch_items(const RenderArgs& args, hipStream_t stream);
+hipError_t launch_finalize(const RenderArgs& args, hipStream_t stream);
 hipError_t launch_resolve(const float4* accum, uint32_t* fb, uint32_t n, hipStream_t stream);
 hipError_t launch_trace_closest(const DeviceScene& sc, uint32_t stack_entries, const float* d_rays, uint32_t n,
                                 float* d_t, uint32_t* d_prim, hipStream_t stream);

@@ -27,54 +27,87 @@ namespace ptd {
 
 extern __shared__ uint32_t lds_dyn[];
 
-// ---- pixel queue: ballot the idle lanes, one atomic by the first of them, prefix-popcount ----
-struct QueueState { uint32_t shard, shards_left; };
+// ---- pixel queue ---------------------------------------------------------------------------------
+// Work item = (pixel, sample chunk).  k_items tabulates every item of this launch once (pixel
+// coordinates from the tile order of sutil/WorkDistribution.h, seed = tea<4>(pixel, frame) skipped
+// ahead to the chunk's first sample), so taking an item inside the render kernel is one 8-byte load.
+// Grants: the first idle lane (ffs of the ballot) takes max(idle lanes, A.grant) consecutive items of the
+// wave's queue shard with ONE atomicAdd; the wave hands them out by popcount-prefix and keeps the rest as a
+// reserve, so most refills touch no atomic at all.  Shards are per XCD; drained shards are stolen
+// from round-robin.
+constexpr uint32_t kNoItem = 0xFFFFFFFFu;
+
+__global__ void k_items(const RenderArgs A)
+{
+    const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= A.total_samples) return;
+    const uint32_t chunk = item & ((1u << A.chunk_shift) - 1u);
+    int x, y;
+    sample_pixel(A.world, (int)A.width, A.rank, (int)(item >> A.chunk_shift), x, y);
+    uint2 r = make_uint2(kNoItem, 0u);
+    if ((uint32_t)x < A.width && (uint32_t)y < A.height) {
+        const uint32_t pix = (uint32_t)y * A.width + (uint32_t)x;
+        // :721, then skip the jitter draws of the samples before this chunk (2 per sample)
+        r = make_uint2((uint32_t)x | ((uint32_t)y << 16), A.lcg_mul[chunk] * tea4(pix, A.frame) + A.lcg_add[chunk]);
+    }
+    A.items[item] = r;
+}
+
+struct QueueState { uint32_t shard, shards_left, res_first, res_count; };
 
 struct LanePixel {
     bool alive, new_path;
     uint32_t pix, px, py, seed, samples_left;
+    uint32_t chunk;      // which run of the pixel's samples this lane owns (0 when chunking is off)
     f3 result;
 };
 
 __device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q, uint32_t lane, unsigned long long below, LanePixel& lp)
 {
     unsigned long long idle = __ballot(!lp.alive);
-    while (idle != 0ull && q.shards_left != 0u) {
+    while (idle != 0ull && (q.res_count != 0u || q.shards_left != 0u)) {
+        if (q.res_count == 0u) {                                      // wave-uniform: fetch a grant
+            const uint32_t leader = (uint32_t)__ffsll((long long)idle) - 1u;
+            const uint32_t idle_n = (uint32_t)__popcll(idle);
+            const uint32_t req = idle_n > A.grant ? idle_n : A.grant;   // at least what is needed now
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&A.queue_heads[q.shard], req);
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+            const uint32_t shard_begin = q.shard * A.shard_size;
+            uint32_t shard_end = shard_begin + A.shard_size;
+            if (shard_end > A.total_samples) shard_end = A.total_samples;
+            if (shard_begin > A.total_samples) shard_end = shard_begin;
+            const uint32_t first = shard_begin + base;
+            uint32_t avail = first < shard_end ? shard_end - first : 0u;
+            if (avail > req) avail = req;
+            if (avail < req) { q.shard = (q.shard + 1u) & 7u; q.shards_left--; }   // shard drained: steal from the next
+            q.res_first = first; q.res_count = avail;
+            if (avail == 0u) continue;
+        }
         const uint32_t want = (uint32_t)__popcll(idle);
-        const uint32_t leader = (uint32_t)__ffsll((long long)idle) - 1u;
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&A.queue_heads[q.shard], want);
-        base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);   // wave-uniform
-        const uint32_t shard_begin = q.shard * A.shard_size;
-        uint32_t shard_end = shard_begin + A.shard_size;
-        if (shard_end > A.total_samples) shard_end = A.total_samples;
-        if (shard_begin > A.total_samples) shard_end = shard_begin;
-        const uint32_t first = shard_begin + base;
-        const uint32_t avail = first < shard_end ? shard_end - first : 0u;
-        if (!lp.alive) {
-            const uint32_t rank = (uint32_t)__popcll(idle & below);
-            if (rank < avail) {
-                int x, y;
-                sample_pixel(A.world, (int)A.width, A.rank, (int)(first + rank), x, y);
-                if ((uint32_t)x < A.width && (uint32_t)y < A.height) {
-                    lp.px = (uint32_t)x; lp.py = (uint32_t)y;
-                    lp.pix = lp.py * A.width + lp.px;
-                    lp.seed = tea4(lp.pix, A.frame);                  // :721
-                    lp.result = mk(0.0f);
-                    lp.samples_left = A.spp;
-                    lp.alive = true;
-                    lp.new_path = true;
-                }
+        const uint32_t take = want < q.res_count ? want : q.res_count;
+        const uint32_t rank = (uint32_t)__popcll(idle & below);
+        if (!lp.alive && rank < take) {
+            const uint32_t item = q.res_first + rank;
+            const uint2 it = A.items[item];
+            if (it.x != kNoItem) {
+                lp.px = it.x & 0xFFFFu; lp.py = it.x >> 16;
+                lp.pix = lp.py * A.width + lp.px;
+                lp.chunk = item & ((1u << A.chunk_shift) - 1u);
+                lp.seed = it.y;
+                lp.result = mk(0.0f);
+                lp.samples_left = A.chunk_spp;
+                lp.alive = true;
+                lp.new_path = true;
             }
         }
-        if (avail < want) { q.shard = (q.shard + 1u) & 7u; q.shards_left--; }   // shard drained: steal from the next
-        idle = __ballot(!lp.alive);
-        if (avail >= want) break;   // everyone who asked was served (padding pixels retry next turn)
+        q.res_first += take; q.res_count -= take;
+        idle = __ballot(!lp.alive);          // lanes that drew a padding item try again
     }
 }
 
-// pixel finished: mean over spp, progressive lerp, float4 + sRGB write (:782-814)
-__device__ __forceinline__ void write_pixel(const RenderArgs& A, uint32_t pix, const f3& result)
+// mean over spp, progressive lerp, float4 + sRGB write (:782-814)
+__device__ __forceinline__ void resolve_pixel(const RenderArgs& A, uint32_t pix, const f3& result)
 {
     f3 accum = result / (float)A.spp;
     if (A.frame > 0u) {
@@ -84,6 +117,29 @@ __device__ __forceinline__ void write_pixel(const RenderArgs& A, uint32_t pix, c
     }
     A.accum[pix] = make_float4(accum.x, accum.y, accum.z, 1.0f);
     if (A.fb) A.fb[pix] = make_color(accum);
+}
+
+// a lane has finished its run of samples: either the whole pixel (write it) or one chunk (park the
+// partial sum; k_finalize adds the chunks in chunk order)
+__device__ __forceinline__ void write_pixel(const RenderArgs& A, const LanePixel& lp)
+{
+    if (A.chunk_shift == 0u) resolve_pixel(A, lp.pix, lp.result);
+    else A.partial[((size_t)lp.pix << A.chunk_shift) + lp.chunk] = make_float4(lp.result.x, lp.result.y, lp.result.z, 0.0f);
+}
+
+// chunked launches: sum the partial sums of every pixel of this rank in chunk order, then resolve
+__global__ void k_finalize(const RenderArgs A)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= (A.total_samples >> A.chunk_shift)) return;
+    int x, y;
+    sample_pixel(A.world, (int)A.width, A.rank, (int)slot, x, y);
+    if ((uint32_t)x >= A.width || (uint32_t)y >= A.height) return;
+    const uint32_t pix = (uint32_t)y * A.width + (uint32_t)x;
+    const float4* p = A.partial + ((size_t)pix << A.chunk_shift);
+    f3 sum = mk(p[0].x, p[0].y, p[0].z);
+    for (uint32_t k = 1; k < (1u << A.chunk_shift); k++) sum += mk(p[k].x, p[k].y, p[k].z);
+    resolve_pixel(A, pix, sum);
 }
 
 __device__ __forceinline__ ShadeConsts shade_consts(const RenderArgs& A)
@@ -112,10 +168,10 @@ k_render(const RenderArgs A)
     const float fw = (float)(int)A.width, fh = (float)(int)A.height;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-    QueueState q; q.shard = xcc_id(); q.shards_left = 8;
+    QueueState q; q.shard = xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0;
     unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0;
 
-    LanePixel lp; lp.alive = false; lp.new_path = false; lp.pix = lp.px = lp.py = lp.seed = lp.samples_left = 0; lp.result = mk(0.0f);
+    LanePixel lp; lp.alive = false; lp.new_path = false; lp.pix = lp.px = lp.py = lp.seed = lp.samples_left = lp.chunk = 0; lp.result = mk(0.0f);
     uint32_t pseed = 0;
     int depth = 0;
     f3 org = mk(0.0f), dir = mk(0.0f, 0.0f, 1.0f), att = mk(1.0f);
@@ -123,7 +179,7 @@ k_render(const RenderArgs A)
     for (;;) {
         refill_lanes(A, q, lane, below, lp);
         const unsigned long long live = __ballot(lp.alive);
-        if (live == 0ull) { if (q.shards_left == 0u) break; else continue; }
+        if (live == 0ull) { if (q.shards_left == 0u && q.res_count == 0u) break; else continue; }
 
         if (lp.alive && lp.new_path) {                                // camera path start, :727-745
             const float jx = rnd(lp.seed);
@@ -173,7 +229,7 @@ k_render(const RenderArgs A)
             } else {
                 lp.samples_left--;
                 lp.new_path = true;
-                if (lp.samples_left == 0u) { write_pixel(A, lp.pix, lp.result); lp.alive = false; finished = true; }
+                if (lp.samples_left == 0u) { write_pixel(A, lp); lp.alive = false; finished = true; }
             }
         }
         n_paths += (unsigned long long)__popcll(__ballot(end));
@@ -226,11 +282,11 @@ k_render_pw(const RenderArgs A)
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int root = sc.n_tris ? 0 : kSentinel;
 
-    QueueState q; q.shard = xcc_id(); q.shards_left = 8;
+    QueueState q; q.shard = xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0;
     unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0;
     unsigned long long n_steps = 0, n_lane_steps = 0, n_rounds = 0, n_lane_rounds = 0;
 
-    LanePixel lp; lp.alive = false; lp.new_path = false; lp.pix = lp.px = lp.py = lp.seed = lp.samples_left = 0; lp.result = mk(0.0f);
+    LanePixel lp; lp.alive = false; lp.new_path = false; lp.pix = lp.px = lp.py = lp.seed = lp.samples_left = lp.chunk = 0; lp.result = mk(0.0f);
     uint32_t pseed = 0;
     int depth = 0;
     f3 att = mk(1.0f);
@@ -289,14 +345,14 @@ k_render_pw(const RenderArgs A)
             } else {
                 lp.samples_left--;
                 lp.new_path = true;
-                if (lp.samples_left == 0u) { write_pixel(A, lp.pix, lp.result); lp.alive = false; finished = true; }
+                if (lp.samples_left == 0u) { write_pixel(A, lp); lp.alive = false; finished = true; }
             }
         }
         n_paths += (unsigned long long)__popcll(__ballot(end));
         n_pixels += (unsigned long long)__popcll(__ballot(finished));
 
         refill_lanes(A, q, lane, below, lp);
-        if (__ballot(lp.alive) == 0ull) { if (q.shards_left == 0u) break; else continue; }
+        if (__ballot(lp.alive) == 0ull) { if (q.shards_left == 0u && q.res_count == 0u) break; else continue; }
 
         bool start_radiance = segment_done && !end;
         if (lp.alive && lp.new_path) {                                // camera path start, :727-745
@@ -435,6 +491,19 @@ __global__ void k_resolve(const float4* __restrict__ accum, uint32_t* __restrict
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { const float4 a = accum[i]; fb[i] = make_color(mk(a.x, a.y, a.z)); }
+}
+
+hipError_t launch_items(const RenderArgs& args, hipStream_t stream)
+{
+    k_items<<<(args.total_samples + 255) / 256, 256, 0, stream>>>(args);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize(const RenderArgs& args, hipStream_t stream)
+{
+    const uint32_t slots = args.total_samples >> args.chunk_shift;
+    k_finalize<<<(slots + 255) / 256, 256, 0, stream>>>(args);
+    return hipGetLastError();
 }
 
 hipError_t launch_resolve(const float4* accum, uint32_t* fb, uint32_t n, hipStream_t stream)

@@ -169,6 +169,11 @@ def main():
 
     for w in range(a.warmup):
         step(w)
+    if world > 1:          # bring up the RCCL channels of the reduce outside the timed region
+        if rehearse:
+            host = accum.cpu(); D.reduce_accumulation(host, dst=0)
+        else:
+            D.reduce_accumulation(accum, dst=0)
     accum.zero_()
 
     # ---- timed region ---------------------------------------------------------------------------

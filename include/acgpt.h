@@ -95,6 +95,8 @@ typedef struct pt_stats {
     float    launch_ms;       /* pt_launch entry -> synchronised return       */
     uint32_t pixels;          /* pixels this launch rendered (tile partition) */
     uint32_t grid_blocks;     /* persistent workgroups launched                */
+    uint32_t sample_chunks;   /* runs per pixel this launch used (pt_set_sample_chunks) */
+    uint32_t reserved;
     /* scheduler diagnostics (0 for the segment-synchronous variant):          */
     uint64_t trav_wave_steps;   /* BVH loop iterations summed over waves       */
     uint64_t trav_lane_steps;   /* ... times lanes with a ray in flight        */
@@ -164,6 +166,16 @@ int pt_set_partition(pt_ctx* ctx, int rank, int world);
  * make_color (cuda/helpers.h:58-63, as pathTracerPrograms.cu:814 does per pixel) to n_pixels of
  * a float4 DEVICE array and writes uchar4 into frameBuffer (device or mapped host).          */
 int pt_resolve_framebuffer(pt_ctx* ctx, const float* accumulation_rgba, uint8_t* framebuffer_rgba, size_t n_pixels);
+
+/* Sample chunks (1, 2, 4, 8, 16; 0 = automatic, the default: 8, or 16 when this rank holds fewer
+ * than 2^20 pixels, reduced until every run keeps at least 4 samples).  With c > 1 a pixel's samplesPerPixel samples are cut into
+ * c consecutive runs, each owned by its own lane with the PRNG skipped ahead to where the run
+ * starts, and the runs' partial sums are added in run order.  Same samples, same paths; only the
+ * association of the fp32 sum changes ((s1+..+sk) + (sk+1+..) instead of one left-to-right chain), so
+ * images differ from c = 1 in the last bits.  It shortens the per-pixel serial chain, which is what
+ * bounds a launch when a GPU holds few pixels (multi-GPU tiles), and keeps neighbouring lanes on
+ * similar rays.  c = 1 is the reference's own left-to-right sum.  samplesPerPixel must divide by c. */
+int pt_set_sample_chunks(pt_ctx* ctx, int chunks);
 
 /* Launch tuning: persistent workgroups per CU (0 = from the occupancy query) and the render
  * kernel variant (0 = segment-synchronous, n >= 1 = persistent traversal with deferred shading,

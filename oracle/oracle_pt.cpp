@@ -23,7 +23,7 @@
  * PARITY PINNING.  cuda/random.h, cuda/helpers.h, sutil/vec_math.h, sutil/Camera.cpp
  * and PathTracer_Optix/TinyObjWrapper.cpp compile here from where they lie (recipe:
  * oracle/Makefile -> oracle/_ref/libref.so) and this restatement is checked against
- * them function by function (tests/test_oracle_vs_ref.py, fixtures in tests/golden/).
+ * them function by function (tests/test_oracle_golden.py, fixtures in tests/golden/).
  * pathTracerPrograms.cu itself needs <optix.h>, which this image does not have, so the
  * three OptiX programs are UNBUILDABLE here and the reference ships no test or golden
  * vector for them: for the raygen/closest-hit/miss glue, PARITY IS UNPINNED — it is a
@@ -530,7 +530,7 @@ static inline void closesthit(const Scene& sc, const pt_params& params, int use_
 }
 
 /* __raygen__rg, pathTracerPrograms.cu:707-816, for launch index (x, y) */
-static void raygen_pixel(const Scene& sc, const pt_params& params, int use_bvh, uint32_t x, uint32_t y,
+static void raygen_pixel(const Scene& sc, const pt_params& params, int use_bvh, int chunks, uint32_t x, uint32_t y,
                          float* accumulation, uint8_t* framebuffer, Counters& cnt)
 {
     const int w = params.width, h = params.height;
@@ -539,8 +539,14 @@ static void raygen_pixel(const Scene& sc, const pt_params& params, int use_bvh, 
     const unsigned maxDepth = params.maxDepth;
 
     uint32_t seed = tea4(y * w + x, subframe_index);               /* :721 */
+    // `chunks` > 1 is NOT the reference: the same samples in the same order, but summed as `chunks`
+    // consecutive runs whose partial sums are then added in run order (the association the product's
+    // pt_set_sample_chunks() uses).  chunks == 1 is the reference's single left-to-right sum (:760-761).
+    f3 total = mk(0.0f);
     f3 result = mk(0.0f);
     int i = params.samplesPerPixel;
+    const int run = (int)params.samplesPerPixel / (chunks > 0 ? chunks : 1);
+    int in_run = 0, runs_done = 0;
     PRD prd; memset(&prd, 0, sizeof(prd));
     do {
         /* :730 make_float2(rnd(seed), rnd(seed)): left-to-right, x first */
@@ -577,7 +583,12 @@ static void raygen_pixel(const Scene& sc, const pt_params& params, int use_bvh, 
             ray_direction = prd.direction;
             ++prd.depth;
         }
+        if (chunks > 1 && ++in_run == run) {
+            total = runs_done == 0 ? result : total + result;
+            result = mk(0.0f); in_run = 0; runs_done++;
+        }
     } while (--i);
+    if (chunks > 1) result = total;
 
     const uint32_t image_index = y * params.width + x;
     f3 accum_color = result / (float)params.samplesPerPixel;        /* :784 */
@@ -719,10 +730,11 @@ ORC_API void orc_trace_any(void* s, const float* rays, size_t n, int use_bvh, ui
 
 /* One launch (LaunchCurrentFrame, PathTracerMain.cpp:184-210) on the host.
  * accumulation / framebuffer are HOST arrays here (params->accumulationBuffer and
- * ->frameBuffer are ignored).  rank/world select the WorkDistribution partition.
+ * ->frameBuffer are ignored).  rank/world select the WorkDistribution partition; chunks: see raygen_pixel
+ * (1 = the reference's summation order).
  * stats_out: radiance_rays, shadow_rays, paths.  Returns wall seconds. */
 ORC_API double orc_render(void* s, const pt_params* params, float* accumulation, uint8_t* framebuffer,
-                          int use_bvh, int n_threads, int rank, int world, uint64_t* stats_out)
+                          int use_bvh, int n_threads, int rank, int world, int chunks, uint64_t* stats_out)
 {
     const Scene& sc = *(Scene*)s;
     const int w = params->width, h = params->height;
@@ -742,7 +754,7 @@ ORC_API double orc_render(void* s, const pt_params* params, float* accumulation,
             for (int si = b; si < e; si++) {
                 int px, py; sample_pixel(world, w, rank, si, px, py);
                 if (px >= w || py >= h) continue;
-                raygen_pixel(sc, *params, use_bvh, (uint32_t)px, (uint32_t)py, accumulation, framebuffer, c);
+                raygen_pixel(sc, *params, use_bvh, chunks, (uint32_t)px, (uint32_t)py, accumulation, framebuffer, c);
             }
         }
         cnts[tid] = c;

@@ -3,7 +3,7 @@
  * they lie under /root/reference (never copied).  Builds only in the authoring container
  * (the reference does not exist on the GPU box); output goes to oracle/_ref/libref.so,
  * which is git-ignored.  Used by tests/golden/make_golden.py to generate fixtures and by
- * tests/test_oracle_vs_ref.py to pin oracle_pt.cpp function by function.
+ * tests/test_oracle_golden.py to pin oracle_pt.cpp function by function.
  *
  * TEST INFRASTRUCTURE, NOT PRODUCT.
  *

@@ -34,9 +34,12 @@ def gpu_state_factory():
     import acgpathtracing_amd as pt
     made = []
 
-    def make(obj_path, **kw):
+    def make(obj_path, sample_chunks=1, **kw):
+        """sample_chunks=1: the reference's own summation order (what most parity tests want)."""
+        from acgpathtracing_amd import _native
         state, obj = pt.setup(obj_path, **kw)
         made.append(state)
+        assert _native.hip().pt_set_sample_chunks(state.context, sample_chunks) == 0
         return state, obj
 
     yield make

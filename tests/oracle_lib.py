@@ -38,7 +38,7 @@ class Oracle:
         L.orc_scene_destroy.argtypes = [vp]; L.orc_scene_destroy.restype = None
         L.orc_trace_closest.argtypes = [vp, vp, sz, C.c_int, vp, vp]; L.orc_trace_closest.restype = None
         L.orc_trace_any.argtypes = [vp, vp, sz, C.c_int, vp]; L.orc_trace_any.restype = None
-        L.orc_render.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]; L.orc_render.restype = C.c_double
+        L.orc_render.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]; L.orc_render.restype = C.c_double
         L.orc_uses_hw_fma.argtypes = []; L.orc_uses_hw_fma.restype = C.c_int
 
     # -- small functions -------------------------------------------------------------
@@ -124,7 +124,7 @@ class OracleScene:
         self.orc.lib.orc_trace_any(self.h, rays.ctypes.data, rays.shape[0], int(use_bvh), o.ctypes.data)
         return o
 
-    def render(self, params, accumulation=None, use_bvh=True, threads=0, rank=0, world=1):
+    def render(self, params, accumulation=None, use_bvh=True, threads=0, rank=0, world=1, chunks=1):
         """One launch on the CPU.  Returns (accumulation[h,w,4] f32, framebuffer[h,w,4] u8, stats dict, seconds)."""
         h, w = int(params.height), int(params.width)
         if accumulation is None:
@@ -134,7 +134,7 @@ class OracleScene:
         if threads <= 0:
             threads = os.cpu_count() or 1
         secs = self.orc.lib.orc_render(self.h, C.byref(params), accumulation.ctypes.data, fb.ctypes.data,
-                                       int(use_bvh), int(threads), int(rank), int(world), stats.ctypes.data)
+                                       int(use_bvh), int(threads), int(rank), int(world), int(chunks), stats.ctypes.data)
         return accumulation, fb, {"radiance_rays": int(stats[0]), "shadow_rays": int(stats[1]), "paths": int(stats[2])}, float(secs)
 
 

@@ -223,6 +223,36 @@ def test_every_kernel_variant_gives_the_same_bits(full):
     assert tried >= 4
 
 
+@pytest.mark.parametrize("chunks", [2, 8, 16, 0])
+def test_sample_chunks(full, chunks):
+    """pt_set_sample_chunks: the same samples summed as consecutive runs.  Against the oracle with the
+    same association the usual bit-level agreement holds; against the reference's order (chunks = 1)
+    only the last bits of the sums move.  0 = automatic."""
+    state, obj, sc = full
+    L = _native.hip()
+    p = make_params(128, 80, 32, 6, True, True)
+    base, _, base_st = _gpu_render(state, p)                   # chunks = 1
+    try:
+        assert L.pt_set_sample_chunks(state.context, chunks) == 0
+        acc, fb, st = _gpu_render(state, p)
+        used = st[0].sample_chunks
+        assert used == (chunks if chunks else 8) or (chunks == 0 and used in (4, 8, 16))
+        assert (st[0].radiance_rays, st[0].shadow_rays, st[0].paths, st[0].pixels) == \
+               (base_st[0].radiance_rays, base_st[0].shadow_rays, base_st[0].paths, base_st[0].pixels), "same paths, same rays"
+        ref, ref_fb, _, _ = sc.render(copy_params(p), use_bvh=True, chunks=used)
+        assert image_mse(acc, ref) < MSE_TOL
+        assert np.all(acc.view(np.uint32) == ref.view(np.uint32), axis=-1).mean() > 0.50
+        rel = np.abs(acc[..., :3] - base[..., :3]) / np.maximum(np.abs(base[..., :3]), 1e-3)
+        assert rel.max() < 1e-4, "re-association moves sums by ulps only"
+        assert image_mse(acc, base) < 1e-10
+        # 3 samples cannot be cut into 2 runs
+        q = copy_params(state.params); q.samplesPerPixel = 3
+        if chunks > 1:
+            assert L.pt_launch(state.context, C.byref(q)) != 0
+    finally:
+        assert L.pt_set_sample_chunks(state.context, 1) == 0
+
+
 def test_deterministic_and_zero_copy(full):
     """Same inputs -> same bits, and the ZERO_COPY framebuffer mode sees the same pixels."""
     state, obj, _ = full
@@ -240,6 +270,7 @@ def test_tile_partition_is_exact(full, oracle):
     state, obj, _ = full
     L = _native.hip()
     p = make_params(100, 52, 4, 4, True, True)     # neither a multiple of the 16x4 strip nor of 8
+    assert L.pt_set_sample_chunks(state.context, 4) == 0    # the multi-GPU setting: runs of samples per lane
     whole, _, _ = _gpu_render(state, p)
     total = np.zeros_like(whole)
     cover = np.zeros(whole.shape[:2], np.int32)
@@ -267,6 +298,7 @@ def test_tile_partition_is_exact(full, oracle):
                 assert pt.getStats(state).pixels == int(expect.sum())
     finally:
         L.pt_set_partition(state.context, 0, 1)
+        L.pt_set_sample_chunks(state.context, 1)
     assert np.all(cover == 1)
     assert np.array_equal(total.view(np.uint32), whole.view(np.uint32))
 

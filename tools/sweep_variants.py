@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--variants", default="all")
     ap.add_argument("--blocks-per-cu", default="0")
     ap.add_argument("--no-dl", action="store_true")
+    ap.add_argument("--chunks", default="1", help="comma list of sample-chunk counts to sweep")
+    ap.add_argument("--partition", default="0,1", help="rank,world pixel-tile partition")
     ap.add_argument("--build-mode", type=int, default=None, help="0 Karras LBVH, 1 PLOC (library default)")
     a = ap.parse_args()
     L = _native.hip()
@@ -37,13 +39,18 @@ def main():
     keep_a, keep_h = state.params.accumulationBuffer, state.params.handle
     C.memmove(C.byref(state.params), C.byref(p), C.sizeof(p))
     state.params.accumulationBuffer, state.params.handle = keep_a, keep_h
+    rank, world = [int(x) for x in a.partition.split(",")]
+    assert L.pt_set_partition(state.context, rank, world) == 0
     info = pt.getBvhInfo(state)
     print("scene %s: %d tris, depth %d, stack %d, build %.2f ms" % (a.scene, info.n_tris, info.max_depth, info.stack_entries, info.build_ms))
     variants = list(range(64)) if a.variants == "all" else [int(v) for v in a.variants.split(",")]
     bpcs = [int(v) for v in a.blocks_per_cu.split(",")]
     results = {}
     ref_hash = None
+    chunk_list = [int(x) for x in a.chunks.split(",")]
     for r in range(a.rounds):
+      for ch in chunk_list:
+        assert L.pt_set_sample_chunks(state.context, ch) == 0
         for bpc in bpcs:
             for v in variants:
                 if L.pt_set_tuning(state.context, bpc, v) != 0:
@@ -57,19 +64,21 @@ def main():
                 h = hashlib.sha1(acc.tobytes()).hexdigest()[:12] if acc is not None else None
                 if ref_hash is None:
                     ref_hash = h
-                key = (v, bpc)
+                key = (v, bpc, ch)
                 e = results.setdefault(key, {"ms": [], "hash": h, "stats": s})
                 e["ms"].append(s.kernel_ms)
-    print("%-4s %-4s %-6s %9s %9s %9s %8s %8s %8s  %s" % ("var", "bpc", "grid", "ms(min)", "ms(med)", "Mray/s", "travEff", "shadeEff", "steps/ray", "bits==v0"))
-    for (v, bpc), e in sorted(results.items()):
+    print("%-4s %-4s %-3s %-6s %9s %9s %9s %8s %8s %8s  %s" % ("var", "bpc", "ch", "grid", "ms(min)", "ms(med)", "Mray/s", "travEff", "shadeEff", "steps/ray", "bits==first"))
+    for (v, bpc, ch), e in sorted(results.items()):
         s = e["stats"]
         rays = s.radiance_rays + s.shadow_rays
         ms = sorted(e["ms"])
         te = s.trav_lane_steps / (64.0 * s.trav_wave_steps) if s.trav_wave_steps else float("nan")
         se = s.shade_lane_rounds / (64.0 * s.shade_wave_rounds) if s.shade_wave_rounds else float("nan")
         spr = s.trav_lane_steps / rays if s.trav_wave_steps else float("nan")
-        print("%-4d %-4d %-6d %9.3f %9.3f %9.1f %8.3f %8.3f %8.2f  %s" %
-              (v, bpc, s.grid_blocks, ms[0], ms[len(ms) // 2], rays / ms[0] / 1e3, te, se, spr, e["hash"] == ref_hash))
+        if s.trav_wave_steps:
+            print("      wave-steps %.4g  shade rounds %.4g  rays %.4g  paths %.4g  pixels %d" % (s.trav_wave_steps, s.shade_wave_rounds, rays, s.paths, s.pixels))
+        print("%-4d %-4d %-3d %-6d %9.3f %9.3f %9.1f %8.3f %8.3f %8.2f  %s" %
+              (v, bpc, ch, s.grid_blocks, ms[0], ms[len(ms) // 2], rays / ms[0] / 1e3, te, se, spr, e["hash"] == ref_hash))
     pt.CleanAllTheThings(state)
 
 
