@@ -6,7 +6,7 @@
 namespace ptd {
 
 constexpr int kRenderThreads = 256;   // 4 waves per workgroup (segment-synchronous variant)
-constexpr int kDefaultVariant = 6;    // persistent traversal, K40 L8, fp32 nodes, 5 waves/SIMD
+constexpr int kDefaultVariant = 1;    // persistent traversal, K40 L8, fp32 nodes, 4 waves/SIMD (no spills)
 
 struct RenderArgs {
     DeviceScene scene;

@@ -551,19 +551,15 @@ struct VariantDesc { RenderKernel k; int threads; int node_fmt; const char* name
 // <SHADE_K, LEAF_K, NODE_FMT, THREADS>.
 static const VariantDesc kVariants[] = {
     {k_render, 256, 0, "sync fp32-nodes"},
-    {k_render_pw<32, 8, 0, 256, 4, true>, 256, 0, "pw K32 L8 fp32 w4 stats"},
+    {k_render_pw<40, 8, 0, 256, 4, false>, 256, 0, "pw K40 L8 fp32 w4 (default)"},
+    {k_render_pw<40, 8, 0, 256, 4, true>, 256, 0, "pw K40 L8 fp32 w4 + scheduler stats"},
     {k_render_pw<32, 8, 0, 256, 4, false>, 256, 0, "pw K32 L8 fp32 w4"},
-    {k_render_pw<32, 8, 0, 256, 5, false>, 256, 0, "pw K32 L8 fp32 w5"},
-    {k_render_pw<40, 4, 0, 256, 5, false>, 256, 0, "pw K40 L4 fp32 w5"},
-    {k_render_pw<40, 12, 0, 256, 5, false>, 256, 0, "pw K40 L12 fp32 w5"},
-    {k_render_pw<40, 8, 0, 256, 5, false>, 256, 0, "pw K40 L8 fp32 w5"},
-    {k_render_pw<32, 8, 1, 256, 4, false>, 256, 1, "pw K32 L8 q16 w4"},
-    {k_render_pw<48, 8, 0, 256, 5, false>, 256, 0, "pw K48 L8 fp32 w5"},
-    {k_render_pw<32, 8, 2, 1024, 4, false>, 1024, 2, "pw K32 L8 q16-LDS 1024t w4"},
-    {k_render_pw<40, 16, 0, 256, 5, false>, 256, 0, "pw K40 L16 fp32 w5"},
-    {k_render_pw<36, 8, 0, 256, 5, false>, 256, 0, "pw K36 L8 fp32 w5"},
-    {k_render_pw<32, 8, 0, 256, 4, false, 1>, 256, 0, "DIAG pw K32 L8 fp32 w4 +12 VALU/step"},
-    {k_render_pw<32, 8, 0, 256, 4, false, 2>, 256, 0, "DIAG pw K32 L8 fp32 w4 +2 loads/step"},
+    {k_render_pw<48, 8, 0, 256, 4, false>, 256, 0, "pw K48 L8 fp32 w4"},
+    {k_render_pw<40, 8, 0, 256, 5, false>, 256, 0, "pw K40 L8 fp32 w5 (register-capped, spills)"},
+    {k_render_pw<40, 8, 1, 256, 4, false>, 256, 1, "pw K40 L8 q16 w4"},
+    {k_render_pw<40, 8, 2, 1024, 4, false>, 1024, 2, "pw K40 L8 q16-LDS 1024t w4"},
+    {k_render_pw<40, 8, 0, 256, 4, false, 1>, 256, 0, "DIAG +12 VALU per inner step"},
+    {k_render_pw<40, 8, 0, 256, 4, false, 2>, 256, 0, "DIAG +2 loads per inner step"},
 };
 int render_variant_count() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
 const char* render_variant_name(int v) { return (v >= 0 && v < render_variant_count()) ? kVariants[v].name : "?"; }

@@ -18,7 +18,7 @@ from scene_utils import adversarial_rays, copy_params, image_mse, make_params, r
 pytestmark = pytest.mark.gpu
 
 MSE_TOL = 1e-3          # north_star: image L2 error vs reference < 1e-3
-_DEFAULT_VARIANT = 6    # render_megakernel.h: kDefaultVariant
+_DEFAULT_VARIANT = 1    # render_megakernel.h: kDefaultVariant
 SCENE_FULL = pt.SCENES + "/cornell_box.obj"
 SCENE_DIFFUSE = pt.SCENES + "/cornell_box_diffuse.obj"
 
