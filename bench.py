@@ -213,7 +213,9 @@ def main():
         achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
         traffic = None
         prof = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(prof):
+        default_workload = (a.config == 2 and a.scene == "cornell_box_diffuse.obj" and (a.width, a.height, a.spp, a.max_depth) == (WIDTH, HEIGHT, SPP_PER_LAUNCH, MAX_DEPTH)
+                            and world == 1 and a.variant < 0 and not a.blocks_per_cu)
+        if default_workload and os.path.exists(prof):     # PMC traffic was collected on exactly this workload
             try:
                 traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
             except Exception:
