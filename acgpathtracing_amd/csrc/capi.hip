@@ -177,7 +177,7 @@ PT_API int pt_set_partition(pt_ctx* c, int rank, int world)
 PT_API int pt_set_sample_chunks(pt_ctx* c, int chunks)
 {
     if (!c) return fail(nullptr, "pt_set_sample_chunks: null context");
-    if (chunks != 0 && chunks != 1 && chunks != 2 && chunks != 4 && chunks != 8 && chunks != 16) return fail(c, "pt_set_sample_chunks: 0 (automatic), 1, 2, 4, 8 or 16");
+    if (chunks != 0 && chunks != 1 && chunks != 2 && chunks != 4 && chunks != 8 && chunks != 16 && chunks != 32) return fail(c, "pt_set_sample_chunks: 0 (automatic), 1, 2, 4, 8, 16 or 32");
     c->chunks = chunks;
     return 0;
 }
@@ -254,20 +254,21 @@ PT_API int pt_launch(pt_ctx* c, const pt_params* p)
         if (p->samplesPerPixel % (uint32_t)c->chunks != 0u) return fail(c, "pt_launch: samplesPerPixel is not a multiple of the sample-chunk count");
         while ((1 << a.chunk_shift) < c->chunks) a.chunk_shift++;
     } else {
-        // automatic: 8 runs per pixel (16 when this rank holds few pixels), as long as every run keeps >= 4 samples
+        // automatic: 8 runs per pixel, 16 / 32 when this rank holds few pixels (shorter items keep the
+        // tail of the launch short), as long as every run keeps >= 4 samples
         const uint32_t my_pixels = (uint32_t)(((uint64_t)p->width * p->height) / (uint64_t)c->world);
-        uint32_t want = my_pixels < (1u << 20) ? 4u : 3u;
+        uint32_t want = my_pixels < (1u << 19) ? 5u : (my_pixels < (1u << 20) ? 4u : 3u);
         while (want > 0u && (p->samplesPerPixel % (1u << want) != 0u || (p->samplesPerPixel >> want) < 4u)) want--;
         a.chunk_shift = want;
     }
     // reserve per queue atomic: smaller while items are long (a parked reserve lengthens the tail of the
     // launch), larger as the items get shorter and refills more frequent
-    static const uint32_t grant_by_shift[5] = {16u, 16u, 32u, 64u, 64u};
+    static const uint32_t grant_by_shift[6] = {16u, 16u, 32u, 64u, 64u, 64u};
     a.grant = grant_by_shift[a.chunk_shift];
     a.chunk_spp = p->samplesPerPixel >> a.chunk_shift;
     {   // LCG skip-ahead: chunk k starts 2 * k * chunk_spp draws after the pixel seed (two jitter draws per sample, :730)
         uint32_t mul = 1u, add = 0u;
-        for (uint32_t k = 0; k < 16u; k++) {
+        for (uint32_t k = 0; k < 32u; k++) {
             a.lcg_mul[k] = mul; a.lcg_add[k] = add;
             for (uint32_t i = 0; i < 2u * a.chunk_spp; i++) { add = 1664525u * add + 1013904223u; mul = 1664525u * mul; }
         }

@@ -27,8 +27,8 @@ struct RenderArgs {
     // owned by its own lane (shortens the per-pixel serial chain when a GPU has few pixels).
     uint32_t  chunk_shift;     // 0 = one lane per pixel (the reference's summation order)
     uint32_t  chunk_spp;       // spp >> chunk_shift
-    uint32_t  lcg_mul[16];     // seed of chunk k = lcg_mul[k] * seed0 + lcg_add[k]  (2 * k * chunk_spp LCG steps)
-    uint32_t  lcg_add[16];
+    uint32_t  lcg_mul[32];     // seed of chunk k = lcg_mul[k] * seed0 + lcg_add[k]  (2 * k * chunk_spp LCG steps)
+    uint32_t  lcg_add[32];
     float4*   partial;         // [pixel][chunk] partial sums, used when chunk_shift > 0
     uint32_t  grant;           // minimum work items taken per queue atomic (1 = exactly what is needed)
     uint2*    items;           // [total_samples] work items of this launch: {px | py << 16, seed} (k_items)

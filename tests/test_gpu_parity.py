@@ -223,7 +223,7 @@ def test_every_kernel_variant_gives_the_same_bits(full):
     assert tried >= 4
 
 
-@pytest.mark.parametrize("chunks", [2, 8, 16, 0])
+@pytest.mark.parametrize("chunks", [2, 8, 32, 0])
 def test_sample_chunks(full, chunks):
     """pt_set_sample_chunks: the same samples summed as consecutive runs.  Against the oracle with the
     same association the usual bit-level agreement holds; against the reference's order (chunks = 1)
@@ -236,7 +236,7 @@ def test_sample_chunks(full, chunks):
         assert L.pt_set_sample_chunks(state.context, chunks) == 0
         acc, fb, st = _gpu_render(state, p)
         used = st[0].sample_chunks
-        assert used == (chunks if chunks else 8) or (chunks == 0 and used in (4, 8, 16))
+        assert used == (chunks if chunks else 8)      # automatic: 32 runs wanted for a small image, capped so that a run keeps >= 4 of the 32 samples
         assert (st[0].radiance_rays, st[0].shadow_rays, st[0].paths, st[0].pixels) == \
                (base_st[0].radiance_rays, base_st[0].shadow_rays, base_st[0].paths, base_st[0].pixels), "same paths, same rays"
         ref, ref_fb, _, _ = sc.render(copy_params(p), use_bvh=True, chunks=used)
