@@ -16,7 +16,7 @@ HOST = os.path.join(PKG, "host")
 
 HIP_SOURCES = ["capi.hip", "lbvh_build.hip", "render_megakernel.hip"]
 HIP_HEADERS = ["pt_device.h", "lbvh_build.h", "render_megakernel.h"]
-HOST_SOURCES = ["host_capi.cpp", "TinyObjWrapper.cpp", "Camera.cpp", "Trackball.cpp"]
+HOST_SOURCES = ["host_capi.cpp", "TinyObjWrapper.cpp", "Camera.cpp", "Trackball.cpp", "ImageIO.cpp"]
 
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden", "-std=c++17"]
 HOST_FLAGS = ["-O2", "-std=c++14", "-fPIC", "-shared", "-ffp-contract=off", "-fvisibility=hidden"]

@@ -140,5 +140,6 @@ def host():
     L.pth_camera_uvw.argtypes = [vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]; L.pth_camera_uvw.restype = None
     L.pth_trackball_script.argtypes = [vp, vp, vp, C.c_float, C.c_float, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, vp, sz, vp]
     L.pth_trackball_script.restype = None
+    L.pth_save_image.argtypes = [C.c_char_p, vp, C.c_int, C.c_int]; L.pth_save_image.restype = C.c_int
     _host = L
     return L

@@ -3,6 +3,7 @@
 #include <cstdint>
 #include <cstring>
 #include "Camera.h"
+#include "ImageIO.h"
 #include "TinyObjWrapper.h"
 #include "Trackball.h"
 
@@ -70,4 +71,10 @@ HOST_API void pth_trackball_script(const float* eye, const float* lookat, const 
     }
     float3 a = cam.eye(), b = cam.lookat(), c = cam.up();
     out9[0] = a.x; out9[1] = a.y; out9[2] = a.z; out9[3] = b.x; out9[4] = b.y; out9[5] = b.z; out9[6] = c.x; out9[7] = c.y; out9[8] = c.z;
+}
+
+// rgba: width*height*4 bytes, row 0 = bottom; suffix selects PPM or PNG (sutil::saveImage conventions)
+HOST_API int pth_save_image(const char* path, const unsigned char* rgba, int width, int height)
+{
+    return saveImage(path, rgba, width, height) ? 0 : 1;
 }

@@ -344,6 +344,15 @@ def readAccumulation(state):
     return out
 
 
+def saveImage(filename, rgba):
+    """sutil::saveImage conventions (sutil/sutil.cpp:542-655): `rgba` is uint8 [height, width, 4] with row 0
+    at the BOTTOM; the file is written top-down; alpha is dropped.  Suffix .ppm or .png."""
+    a = np.ascontiguousarray(rgba, np.uint8)
+    h, w = a.shape[0], a.shape[1]
+    if _native.host().pth_save_image(os.fsencode(filename), a.ctypes.data, w, h) != 0:
+        raise PathTracerError("cannot write %s" % filename)
+
+
 def keyCallback(state, key):
     """PathTracerMain.cpp:100-141.  key: '0' direct lighting, '1' importance sampling,
     'UP' / 'DOWN' max depth +-1 clamped to [1, 28], 'R' reset.  Every change resets accumulation."""

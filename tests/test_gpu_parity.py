@@ -377,3 +377,31 @@ def test_large_scene_properties(gpu_state_factory, oracle, tmp_path):
     ref, _, ref_st, _ = sc.render(copy_params(p), use_bvh=True)
     assert image_mse(acc, ref) < MSE_TOL
     assert abs(int(st[0].radiance_rays) - ref_st["radiance_rays"]) <= 5e-3 * ref_st["radiance_rays"]
+
+
+def test_headless_app_matches_the_python_path(full, tmp_path):
+    """acgpt_main (the C++ mirror of PathTracerMain.cpp) and the Python mirror drive the same library: the
+    same frames, the same bytes — including the key replay (toggle importance sampling, reset)."""
+    import os
+    import subprocess
+    from PIL import Image
+    exe = os.path.join(os.path.dirname(_native.hip_library_path()), "acgpt_main")
+    if not os.path.exists(exe):
+        from acgpathtracing_amd import _build
+        _build.build_main()
+    out = str(tmp_path / "app.ppm")
+    r = subprocess.run([exe, "--obj", SCENE_FULL, "--width", "96", "--height", "64", "--spp-per-launch", "8", "--frames", "3",
+                        "--max-depth", "5", "--direct-lighting", "--keys", "1", "--out", out], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "Using Importance Sampling: yes" in r.stdout and "Total Samples 16" in r.stdout   # reset after the toggle: 2 frames x 8
+    got = np.asarray(Image.open(out).convert("RGB"))
+    # the same session through the Python mirror: frame 0 without IS is discarded by the reset
+    state, obj, _ = full
+    L = _native.hip()
+    assert L.pt_set_sample_chunks(state.context, 0) == 0          # the app uses the library defaults
+    try:
+        p = make_params(96, 64, 8, 5, True, True)
+        acc, fb, _ = _gpu_render(state, p, frames=2)
+    finally:
+        assert L.pt_set_sample_chunks(state.context, 1) == 0
+    assert np.array_equal(got, fb[::-1, :, :3])

@@ -89,3 +89,21 @@ def test_key_toggle_state_machine():
     s.refreshAccumulationBuffer = False
     pt.keyCallback(s, "R")
     assert s.refreshAccumulationBuffer
+
+
+def test_image_writers(built, tmp_path):
+    """PPM / PNG writers: bottom-left origin in memory, top-down in the file, alpha dropped
+    (sutil::saveImage, sutil/sutil.cpp:542-655)."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, size=(37, 53, 4), dtype=np.uint8)
+    img[0, :, :3] = (255, 0, 0)                 # bottom row red -> last row of the file
+    for name in ("a.ppm", "a.png"):
+        path = str(tmp_path / name)
+        pt.saveImage(path, img)
+        got = np.asarray(Image.open(path).convert("RGB"))
+        assert got.shape == (37, 53, 3)
+        assert np.array_equal(got, img[::-1, :, :3])
+        assert tuple(got[-1, 0]) == (255, 0, 0)
+    with pytest.raises(pt.PathTracerError):
+        pt.saveImage(str(tmp_path / "a.bmp"), img)
