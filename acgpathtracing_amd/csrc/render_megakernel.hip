@@ -259,7 +259,9 @@ k_render(const RenderArgs A)
 //               fits beside the lane stacks; 1024-thread workgroups so one copy serves 16 waves)
 // DIAG (timing experiments only, never a product variant): 1 = 12 extra dependent VALU per inner
 // step, 2 = two extra 16-byte loads per inner step.
-template <int SHADE_K, int LEAF_K, int NODE_FMT, int THREADS, int MINW, bool STATS, int DIAG = 0>
+// INNER: 0 = stack entirely in LDS, nested branches; 1 = stack top cached in a register (the LDS read of
+// a pop is consumed one push/pop later, off the critical path) and child selection by selects.
+template <int SHADE_K, int LEAF_K, int NODE_FMT, int THREADS, int MINW, bool STATS, int DIAG = 0, int INNER = 0>
 __global__ void __launch_bounds__(THREADS, MINW)
 k_render_pw(const RenderArgs A)
 {
@@ -294,7 +296,7 @@ k_render_pw(const RenderArgs A)
     f3 ro = mk(0.0f), rd = mk(0.0f, 0.0f, 1.0f), rinv = mk(1.0f), gro = mk(0.0f);
     float rtmin = 0.0f, rtmax = 0.0f, best_t = 0.0f;
     int best_slot = -1; uint32_t best_prim = 0xFFFFFFFFu;
-    int node = kSentinel, sp = 0;
+    int node = kSentinel, sp = 0, tos = kSentinel;
     bool shadow_ray = false, shadow_hit = false;
     // held while the shadow ray is in flight
     Pending pd; pd.nxt_org = mk(0.0f); pd.nxt_dir = mk(0.0f, 0.0f, 1.0f); pd.radiance = mk(0.0f); pd.weight = 0.0f; pd.done = true;
@@ -442,17 +444,32 @@ k_render_pw(const RenderArgs A)
                 f0 = fminf(f0, best_t);
                 f1 = fminf(f1, best_t);
                 const bool h0 = n0 <= f0, h1 = n1 <= f1;
-                if (h0 && h1) {
-                    const bool first0 = n0 <= n1;
-                    st.push(sp, first0 ? c1 : c0);
-                    sp++;
-                    node = first0 ? c0 : c1;
-                } else if (h0) {
-                    node = c0;
-                } else if (h1) {
-                    node = c1;
+                if (INNER == 0) {
+                    if (h0 && h1) {
+                        const bool first0 = n0 <= n1;
+                        st.push(sp, first0 ? c1 : c0);
+                        sp++;
+                        node = first0 ? c0 : c1;
+                    } else if (h0) {
+                        node = c0;
+                    } else if (h1) {
+                        node = c1;
+                    } else {
+                        if (sp == 0) node = kSentinel; else { sp--; node = st.pop(sp); }
+                    }
                 } else {
-                    if (sp == 0) node = kSentinel; else { sp--; node = st.pop(sp); }
+                    // elements e_1..e_sp, e_sp in `tos`, e_k (k < sp) in LDS slot k
+                    const bool first0 = n0 <= n1;
+                    const int near_c = (h0 && (first0 || !h1)) ? c0 : c1;
+                    const int far_c = first0 ? c1 : c0;
+                    if (h0 && h1) { st.push(sp, tos); tos = far_c; sp++; }
+                    if (h0 || h1) {
+                        node = near_c;
+                    } else {
+                        node = sp ? tos : kSentinel;
+                        sp = sp ? sp - 1 : 0;
+                        tos = st.pop(sp);
+                    }
                 }
             }
             const bool at_leaf = node < 0;       // kSentinel is positive
@@ -470,7 +487,13 @@ k_render_pw(const RenderArgs A)
                         if (shadow_ray) { shadow_hit = true; stop = true; }
                         else if (t < best_t || (t == best_t && prim < best_prim)) { best_t = t; best_slot = slot; best_prim = prim; }
                     }
-                    if (stop || sp == 0) node = kSentinel; else { sp--; node = st.pop(sp); }
+                    if (INNER == 0) {
+                        if (stop || sp == 0) node = kSentinel; else { sp--; node = st.pop(sp); }
+                    } else {
+                        node = (stop || sp == 0) ? kSentinel : tos;
+                        sp = sp ? sp - 1 : 0;
+                        tos = st.pop(sp);
+                    }
                 }
             }
         }
@@ -551,15 +574,15 @@ struct VariantDesc { RenderKernel k; int threads; int node_fmt; const char* name
 // <SHADE_K, LEAF_K, NODE_FMT, THREADS>.
 static const VariantDesc kVariants[] = {
     {k_render, 256, 0, "sync fp32-nodes"},
-    {k_render_pw<40, 8, 0, 256, 4, false>, 256, 0, "pw K40 L8 fp32 w4 (default)"},
-    {k_render_pw<40, 8, 0, 256, 4, true>, 256, 0, "pw K40 L8 fp32 w4 + scheduler stats"},
-    {k_render_pw<32, 8, 0, 256, 4, false>, 256, 0, "pw K32 L8 fp32 w4"},
-    {k_render_pw<48, 8, 0, 256, 4, false>, 256, 0, "pw K48 L8 fp32 w4"},
-    {k_render_pw<40, 8, 0, 256, 5, false>, 256, 0, "pw K40 L8 fp32 w5 (register-capped, spills)"},
-    {k_render_pw<40, 8, 1, 256, 4, false>, 256, 1, "pw K40 L8 q16 w4"},
-    {k_render_pw<40, 8, 2, 1024, 4, false>, 1024, 2, "pw K40 L8 q16-LDS 1024t w4"},
-    {k_render_pw<40, 8, 0, 256, 4, false, 1>, 256, 0, "DIAG +12 VALU per inner step"},
-    {k_render_pw<40, 8, 0, 256, 4, false, 2>, 256, 0, "DIAG +2 loads per inner step"},
+    {k_render_pw<48, 8, 0, 256, 4, false, 0, 1>, 256, 0, "pw K48 L8 fp32 w4, register stack top (default)"},
+    {k_render_pw<48, 8, 0, 256, 4, true, 0, 1>, 256, 0, "default + scheduler stats"},
+    {k_render_pw<40, 8, 0, 256, 4, false, 0, 1>, 256, 0, "pw K40 L8 fp32 w4, register stack top"},
+    {k_render_pw<48, 8, 0, 256, 4, false>, 256, 0, "pw K48 L8 fp32 w4, LDS-only stack"},
+    {k_render_pw<48, 8, 0, 256, 5, false, 0, 1>, 256, 0, "pw K48 L8 fp32 w5 (register-capped, spills)"},
+    {k_render_pw<48, 8, 1, 256, 4, false, 0, 1>, 256, 1, "pw K48 L8 q16 nodes w4"},
+    {k_render_pw<48, 8, 2, 1024, 4, false, 0, 1>, 1024, 2, "pw K48 L8 q16 nodes in LDS, 1024 threads"},
+    {k_render_pw<48, 8, 0, 256, 4, false, 1, 1>, 256, 0, "DIAG +12 VALU per inner step"},
+    {k_render_pw<48, 8, 0, 256, 4, false, 2, 1>, 256, 0, "DIAG +2 loads per inner step"},
 };
 int render_variant_count() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
 const char* render_variant_name(int v) { return (v >= 0 && v < render_variant_count()) ? kVariants[v].name : "?"; }
