@@ -405,3 +405,63 @@ def test_headless_app_matches_the_python_path(full, tmp_path):
     finally:
         assert L.pt_set_sample_chunks(state.context, 1) == 0
     assert np.array_equal(got, fb[::-1, :, :3])
+
+
+def test_full_size_properties(diffuse):
+    """BASELINE config-2 geometry at its full 1920x1080 / 128 spp per launch: the oracle cannot follow
+    at this size, so: (a) the segment-synchronous kernel and the default kernel agree bit for bit,
+    counters included; (b) the 8-way tile partition sums to the whole image bit for bit; (c) counter
+    identities hold (paths = W*H*spp, pixels = W*H); (d) two consecutive frames follow the running-mean
+    rule exactly: acc_1 == lerp(acc_0, frame_1_alone, 1/2)."""
+    state, obj, _ = diffuse
+    L = _native.hip()
+    W, H, S = 1920, 1080, 128
+    p = make_params(W, H, S, 8, True, True)
+    try:
+        assert L.pt_set_sample_chunks(state.context, 0) == 0
+        acc, fb, st = _gpu_render(state, p)
+        s = st[0]
+        assert s.paths == W * H * S and s.pixels == W * H and s.sample_chunks == 8
+        assert s.radiance_rays >= s.paths and 0 < s.shadow_rays < s.radiance_rays
+        assert np.isfinite(acc).all() and np.all(acc[..., 3] == 1.0)
+        assert 0.05 < float(np.clip(acc[..., :3], 0, 1).mean()) < 0.6
+        # (a) reference scheduler, same bits
+        assert L.pt_set_tuning(state.context, 0, 0) == 0
+        acc0, fb0, st0 = _gpu_render(state, p)
+        assert L.pt_set_tuning(state.context, 0, _DEFAULT_VARIANT) == 0
+        assert np.array_equal(acc0.view(np.uint32), acc.view(np.uint32)) and np.array_equal(fb0, fb)
+        assert (st0[0].radiance_rays, st0[0].shadow_rays) == (s.radiance_rays, s.shadow_rays)
+        # (b) 8 ranks' tiles (each picks 32 runs per pixel automatically -> force the whole-image setting)
+        assert L.pt_set_sample_chunks(state.context, 8) == 0
+        q = make_params(W, H, 16, 8, True, True)                  # lighter: 16 spp
+        whole, _, _ = _gpu_render(state, q)
+        total = np.zeros_like(whole)
+        rays = 0
+        for rank in range(8):
+            assert L.pt_set_partition(state.context, rank, 8) == 0
+            state.refreshAccumulationBuffer = True
+            pt.updateState(None, state)
+            L.pt_device_memset(state.context, state.params.accumulationBuffer, 0, W * H * 16)
+            state.params.currentFrameIdx = 0
+            pt.LaunchCurrentFrame(None, state)
+            total += pt.readAccumulation(state)
+            t = pt.getStats(state)
+            assert t.pixels == W * H // 8
+            rays += t.radiance_rays
+        L.pt_set_partition(state.context, 0, 1)
+        assert np.array_equal(total.view(np.uint32), whole.view(np.uint32))
+        # (d) progressive accumulation identity on two frames
+        two, _, _ = _gpu_render(state, q, frames=2)
+        state.refreshAccumulationBuffer = True
+        pt.updateState(None, state)
+        L.pt_device_memset(state.context, state.params.accumulationBuffer, 0, W * H * 16)
+        state.params.currentFrameIdx = 1          # frame 1 over a zero buffer: lerp(0, f1, 1/2) = f1/2 exactly
+        pt.LaunchCurrentFrame(None, state)
+        half_f1 = pt.readAccumulation(state)[..., :3]
+        f1 = half_f1 * np.float32(2.0)
+        expect = whole[..., :3] + np.float32(0.5) * (f1 - whole[..., :3])
+        assert np.array_equal(expect.astype(np.float32).view(np.uint32), two[..., :3].view(np.uint32))
+    finally:
+        L.pt_set_partition(state.context, 0, 1)
+        L.pt_set_tuning(state.context, 0, _DEFAULT_VARIANT)
+        L.pt_set_sample_chunks(state.context, 1)
