@@ -4,20 +4,22 @@
 // (PathTracer_Optix/pathTracerPrograms.cu:707-816, 866-1031, 833-847) and the OptiX
 // traversal underneath them (:600-613, :660-671).
 //
+// Kernels of one pt_launch, in stream order:
+//   k_items      tabulates the work items (pixel, run of samples) of this launch
+//   k_render_pw  the persistent megakernel (default; k_render = segment-synchronous baseline)
+//   k_finalize   only when a pixel is cut into several runs: adds the runs in order, resolves
+//
 // Scheduling (wave64, persistent):
-//   * the grid is sized to the chip (CUs x resident blocks), never to the image;
-//   * one lane owns one pixel and walks its samplesPerPixel paths in the reference's order
-//     (so the per-pixel fp32 sum is the reference's sum), as a FLAT loop: every iteration
-//     each live lane traces exactly one path segment; a lane whose path ends regenerates the
-//     next camera path in the same iteration, so lanes never wait for the longest path;
-//   * a lane whose pixel is finished is refilled from a global pixel queue: __ballot() of the
-//     idle lanes, one atomicAdd by the first idle lane (ffs), popcount-prefix to hand out
-//     consecutive pixels.  The queue has 8 shards, one per XCD (HW_REG_XCC_ID), so
-//     neighbouring pixels share an L2 and the atomics do not contend; empty shards are
-//     stolen from round-robin;
-//   * the BVH traversal stack lives in LDS, entry-major (pt_device.h), sized from the
-//     measured tree height.
-// Pixel order inside the queue is the 8x4-tile order of sutil/WorkDistribution.h:60-81 for
+//   * the grid is sized to the chip (CUs x resident workgroups), never to the image;
+//   * one lane owns one work item and walks its samples in the reference's order as a FLAT loop;
+//     a lane whose path ends regenerates the next camera path right away, a lane whose item is
+//     finished takes the next one from the queue (ballot of the idle lanes, one atomicAdd by the
+//     first of them, popcount-prefix hand-out, wave-local reserve); 8 queue shards, one per XCD;
+//   * radiance and shadow rays share one BVH loop; lanes with a finished ray park until enough of
+//     them are waiting, then that batch is shaded and re-armed (k_render_pw);
+//   * the traversal stack lives in LDS, entry-major (pt_device.h), sized from the measured tree
+//     height, with its top element cached in a register.
+// Item order inside the queue is the 8x4-tile order of sutil/WorkDistribution.h:60-81 for
 // (rank, world), which is also the multi-GPU partition.
 #include "pt_device.h"
 #include "render_megakernel.h"
