@@ -203,6 +203,11 @@ PT_API int pt_set_build_mode(pt_ctx* c, int mode)
     return 0;
 }
 
+PT_API const char* pt_variant_name(int variant)
+{
+    return (variant >= 0 && variant < ptd::render_variant_count()) ? ptd::render_variant_name(variant) : nullptr;
+}
+
 PT_API int pt_set_stream(pt_ctx* c, void* s)
 {
     if (!c) return fail(nullptr, "pt_set_stream: null context");

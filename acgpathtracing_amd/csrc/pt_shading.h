@@ -132,6 +132,8 @@ struct Pending {
 
 // __closesthit__diffuse__ch, pathTracerPrograms.cu:866-1031, for one lane.  Returns true when a
 // shadow ray (P, L, 0.01, Ldist - 0.01) has to be traced before the segment can be accounted.
+// TRIG_DIAG (timing experiment only): replaces sinf/cosf/acosf by hardware approximations to price them.
+template <bool TRIG_DIAG = false>
 __device__ __forceinline__ bool shade_hit(const DeviceScene& sc, const ShadeConsts& K, const f3& org, const f3& dir,
                                           float t_hit, int slot, int depth, uint32_t& pseed, f3& att, f3& emission,
                                           Pending& pd, f3& P, f3& L, float& Ldist)
@@ -153,9 +155,14 @@ __device__ __forceinline__ bool shade_hit(const DeviceScene& sc, const ShadeCons
         const float z2 = rnd(s);
         f3 w_in;
         if (K.useIS) {                                                           // :341-353
+            if (TRIG_DIAG) {
+                const float ct = sqrtf(z1), stt = sqrtf(1.0f - z1);
+                w_in = mk(stt * __builtin_amdgcn_cosf(z2), stt * __builtin_amdgcn_sinf(z2), ct);
+            } else {
             const float theta = acosf(sqrtf(z1));
             const float phi = 2.0f * kPIf * z2;
             w_in = mk(sinf(theta) * cosf(phi), sinf(theta) * sinf(phi), cosf(theta));
+            }
         } else {                                                                 // :368-380
             const float phi = 2.0f * kPIf * z2;
             w_in = mk(cosf(phi) * sqrtf(1 - z1 * z1), sinf(phi) * sqrtf(1 - z1 * z1), z1);

@@ -317,7 +317,7 @@ k_render_pw(const RenderArgs A)
                 bool want_shadow = false;
                 f3 P, L; float Ldist;
                 if (best_slot >= 0) {
-                    want_shadow = shade_hit(sc, K, ro, rd, best_t, best_slot, depth, pseed, att, emission, pd, P, L, Ldist);
+                    want_shadow = shade_hit<DIAG == 3>(sc, K, ro, rd, best_t, best_slot, depth, pseed, att, emission, pd, P, L, Ldist);
                 } else {                                              // __miss__ms :833-847
                     pd.radiance = mk(0.0f); pd.weight = 0.0f; pd.done = true;
                 }
@@ -585,6 +585,7 @@ static const VariantDesc kVariants[] = {
     {k_render_pw<48, 8, 2, 1024, 4, false, 0, 1>, 1024, 2, "pw K48 L8 q16 nodes in LDS, 1024 threads"},
     {k_render_pw<48, 8, 0, 256, 4, false, 1, 1>, 256, 0, "DIAG +12 VALU per inner step"},
     {k_render_pw<48, 8, 0, 256, 4, false, 2, 1>, 256, 0, "DIAG +2 loads per inner step"},
+    {k_render_pw<48, 8, 0, 256, 4, false, 3, 1>, 256, 0, "DIAG hardware sin/cos, algebraic acos (wrong bits, timing only)"},
 };
 int render_variant_count() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
 const char* render_variant_name(int v) { return (v >= 0 && v < render_variant_count()) ? kVariants[v].name : "?"; }

@@ -181,6 +181,9 @@ int pt_set_sample_chunks(pt_ctx* ctx, int chunks);
  * kernel variant (0 = segment-synchronous, n >= 1 = persistent traversal with deferred shading,
  * see csrc/render_megakernel.hip).  Every variant produces the same image bits.           */
 int pt_set_tuning(pt_ctx* ctx, int blocks_per_cu, int variant);
+/* Human-readable description of a kernel variant, NULL past the last one.  Names starting with "DIAG"
+ * are timing experiments (some deliberately compute different bits) and are never selected by default. */
+const char* pt_variant_name(int variant);
 
 /* Stream the launches are enqueued on (a hipStream_t, e.g. torch's current
  * stream); NULL restores the context's own stream (PathTracerMain.cpp:161). */

@@ -53,6 +53,8 @@ def main():
         assert L.pt_set_sample_chunks(state.context, ch) == 0
         for bpc in bpcs:
             for v in variants:
+                if L.pt_variant_name(v) is None:
+                    continue
                 if L.pt_set_tuning(state.context, bpc, v) != 0:
                     if r == 0:
                         print("variant %d skipped: %s" % (v, L.pt_last_error(state.context).decode()))
@@ -77,8 +79,8 @@ def main():
         spr = s.trav_lane_steps / rays if s.trav_wave_steps else float("nan")
         if s.trav_wave_steps:
             print("      wave-steps %.4g  shade rounds %.4g  rays %.4g  paths %.4g  pixels %d" % (s.trav_wave_steps, s.shade_wave_rounds, rays, s.paths, s.pixels))
-        print("%-4d %-4d %-3d %-6d %9.3f %9.3f %9.1f %8.3f %8.3f %8.2f  %s" %
-              (v, bpc, ch, s.grid_blocks, ms[0], ms[len(ms) // 2], rays / ms[0] / 1e3, te, se, spr, e["hash"] == ref_hash))
+        print("%-4d %-4d %-3d %-6d %9.3f %9.3f %9.1f %8.3f %8.3f %8.2f  %-5s  %s" %
+              (v, bpc, ch, s.grid_blocks, ms[0], ms[len(ms) // 2], rays / ms[0] / 1e3, te, se, spr, e["hash"] == ref_hash, L.pt_variant_name(v).decode()))
     pt.CleanAllTheThings(state)
 
 
