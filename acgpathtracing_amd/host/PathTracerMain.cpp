@@ -8,13 +8,18 @@
 //   acgpt_main --obj scene.obj [--width 512 --height 512] [--spp-per-launch 128] [--frames 8]
 //              [--max-depth 4] [--direct-lighting] [--importance-sampling] [--device 0]
 //              [--keys "0,1,UP,UP,R"] [--out frame.png] [--dump-every k] [--zero-copy]
+//              [--orbit dx,dy] [--zoom n] [--sample-chunks c] [--build-mode 0|1]
 //
 // --keys replays the reference's key handler (PathTracerMain.cpp:100-141) between frames, one key
 // per frame: 0 = direct lighting, 1 = importance sampling, UP/DOWN = max depth +-1 in [1,28],
 // R = reset, Q = quit; every change resets the accumulation and the frame index.
+// --orbit / --zoom drive the camera through Trackball (sutil/Trackball.cpp:51-137: 0.5 degree per
+// pixel, zoom factor 1.1 per step) before the first frame; the reference includes Trackball but never
+// wires it to an input callback (PathTracerMain.cpp:18, 686-688).
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -148,6 +153,7 @@ int main(int argc, char** argv)
     std::string objfilepath, out = "frame.png", keys;
     int32_t width = 512, height = 512, frames = 8, dump_every = 0;
     bool zero_copy = false;
+    int orbit_dx = 0, orbit_dy = 0, zoom_steps = 0, sample_chunks = 0, build_mode = 1;
     PathTracerState state;
     state.params.useDirectLighting = false;
     state.params.useImportanceSampling = false;
@@ -168,6 +174,10 @@ int main(int argc, char** argv)
         else if (a == "--out") out = next();
         else if (a == "--dump-every") dump_every = atoi(next());
         else if (a == "--zero-copy") zero_copy = true;
+        else if (a == "--orbit") { if (sscanf(next(), "%d,%d", &orbit_dx, &orbit_dy) != 2) { std::cerr << "--orbit dx,dy" << std::endl; return 2; } }
+        else if (a == "--zoom") zoom_steps = atoi(next());
+        else if (a == "--sample-chunks") sample_chunks = atoi(next());
+        else if (a == "--build-mode") build_mode = atoi(next());
         else { std::cerr << "unknown option " << a << std::endl; return 2; }
     }
     if (objfilepath.empty()) { std::cerr << "usage: acgpt_main --obj scene.obj [options]" << std::endl; return 2; }
@@ -181,6 +191,15 @@ int main(int argc, char** argv)
     try {
         initCamera();
         g_camera.setAspectRatio(static_cast<float>(state.params.width) / static_cast<float>(state.params.height));
+        if (orbit_dx || orbit_dy || zoom_steps) {
+            Trackball trackball;
+            trackball.setCamera(&g_camera);
+            trackball.setMoveSpeed(10.0f);
+            trackball.setReferenceFrame(make_float3(1.0f, 0.0f, 0.0f), make_float3(0.0f, 0.0f, 1.0f), make_float3(0.0f, 1.0f, 0.0f));
+            trackball.setGimbalLock(true);
+            if (orbit_dx || orbit_dy) { trackball.startTracking(0, 0); trackball.updateTracking(orbit_dx, orbit_dy, width, height); }
+            for (int z = 0; z < std::abs(zoom_steps); z++) trackball.wheelEvent(zoom_steps > 0 ? 1 : -1);
+        }
         const float3 eye = g_camera.eye();
         state.params.cameraEye = {eye.x, eye.y, eye.z};
         float3 U, V, W;
@@ -190,6 +209,8 @@ int main(int argc, char** argv)
         std::cout << "Using Direct Lighting: " << (state.params.useDirectLighting ? "yes" : "no") << std::endl;
         std::cout << "Using Importance Sampling: " << (state.params.useImportanceSampling ? "yes" : "no") << std::endl;
         createDeviceContext(state);
+        PT_CHECK(state.context, pt_set_build_mode(state.context, build_mode));
+        PT_CHECK(state.context, pt_set_sample_chunks(state.context, sample_chunks));
         buildTheAccelarationStructure(state, obj);
         std::cout << "Acceleration Structure Built" << std::endl;
         initializeTheLaunch(state);

@@ -468,3 +468,20 @@ def test_full_size_properties(diffuse):
         L.pt_set_partition(state.context, 0, 1)
         L.pt_set_tuning(state.context, 0, _DEFAULT_VARIANT)
         L.pt_set_sample_chunks(state.context, 1)
+
+
+def test_trackball_orbit_changes_the_view(tmp_path):
+    """acgpt_main --orbit / --zoom: Trackball -> Camera -> U,V,W -> a different (valid) image."""
+    import os
+    import subprocess
+    from PIL import Image
+    exe = os.path.join(os.path.dirname(_native.hip_library_path()), "acgpt_main")
+    imgs = []
+    for extra in ([], ["--orbit", "60,-30", "--zoom", "2"]):
+        out = str(tmp_path / ("v%d.png" % len(imgs)))
+        r = subprocess.run([exe, "--obj", SCENE_FULL, "--width", "128", "--height", "96", "--spp-per-launch", "16", "--frames", "1",
+                            "--direct-lighting", "--importance-sampling", "--out", out] + extra, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        imgs.append(np.asarray(Image.open(out).convert("RGB")).astype(np.float32))
+    assert imgs[0].shape == (96, 128, 3) and imgs[0].mean() > 10 and imgs[1].mean() > 10
+    assert np.abs(imgs[0] - imgs[1]).mean() > 5.0
