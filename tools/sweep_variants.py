@@ -67,8 +67,9 @@ def main():
                 if ref_hash is None:
                     ref_hash = h
                 key = (v, bpc, ch)
-                e = results.setdefault(key, {"ms": [], "hash": h, "stats": s})
+                e = results.setdefault(key, {"ms": [], "launch": [], "hash": h, "stats": s})
                 e["ms"].append(s.kernel_ms)
+                e["launch"].append(s.launch_ms)
     print("%-4s %-4s %-3s %-6s %9s %9s %9s %8s %8s %8s  %s" % ("var", "bpc", "ch", "grid", "ms(min)", "ms(med)", "Mray/s", "travEff", "shadeEff", "steps/ray", "bits==first"))
     for (v, bpc, ch), e in sorted(results.items()):
         s = e["stats"]
@@ -77,6 +78,9 @@ def main():
         te = s.trav_lane_steps / (64.0 * s.trav_wave_steps) if s.trav_wave_steps else float("nan")
         se = s.shade_lane_rounds / (64.0 * s.shade_wave_rounds) if s.shade_wave_rounds else float("nan")
         spr = s.trav_lane_steps / rays if s.trav_wave_steps else float("nan")
+        if s.trav_wave_steps:
+            pass
+        print("      pt_launch wall (min) %.3f ms vs render kernel %.3f ms" % (min(e["launch"]), ms[0]))
         if s.trav_wave_steps:
             print("      wave-steps %.4g  shade rounds %.4g  rays %.4g  paths %.4g  pixels %d" % (s.trav_wave_steps, s.shade_wave_rounds, rays, s.paths, s.pixels))
         print("%-4d %-4d %-3d %-6d %9.3f %9.3f %9.1f %8.3f %8.3f %8.2f  %-5s  %s" %
