@@ -237,7 +237,7 @@ PT_API int pt_launch(pt_ctx* c, const pt_params* p)
     if (!c || !p) return fail(c, "pt_launch: null argument");
     const auto t0 = std::chrono::steady_clock::now();
     if (p->width == 0 || p->height == 0) return fail(c, "pt_launch: empty image");
-    if ((uint64_t)p->width * p->height > 0x7FFFFFFFull / 8) return fail(c, "pt_launch: image too large");
+    if (p->width > 65535u || p->height > 65535u) return fail(c, "pt_launch: width and height are limited to 65535 (work items pack them into 16 bits each)");
     if (p->samplesPerPixel == 0) return fail(c, "pt_launch: samplesPerPixel must be >= 1 (do{}while(--i), pathTracerPrograms.cu:727,780)");
     if (p->maxDepth < 1 || p->maxDepth > 28) return fail(c, "pt_launch: maxDepth must be in [1, 28] (PathTracerMain.cpp:42, 122-128)");
     if (!p->accumulationBuffer) return fail(c, "pt_launch: accumulationBuffer is null");
@@ -278,6 +278,8 @@ PT_API int pt_launch(pt_ctx* c, const pt_params* p)
             for (uint32_t i = 0; i < 2u * a.chunk_spp; i++) { add = 1664525u * add + 1013904223u; mul = 1664525u * mul; }
         }
     }
+    if (((uint64_t)num_samples(c->world, p->width, p->height) << a.chunk_shift) >= 0x7FFFFFFFull)
+        return fail(c, "pt_launch: image too large for this sample-chunk count (2^31 work items)");
     a.total_samples = num_samples(c->world, p->width, p->height) << a.chunk_shift;
     a.shard_size = ((a.total_samples + 7u) / 8u + 63u) & ~63u;
     {

@@ -327,7 +327,7 @@ def test_edge_cases(gpu_state_factory, oracle, tmp_path):
     assert np.all(acc[..., :3] == 0.0) and np.all(acc[..., 3] == 1.0) and np.all(fb[..., :3] == 0) and np.all(fb[..., 3] == 255)
     assert st[0].radiance_rays == 32 * 32 * 2
     # argument checking (PathTracerMain.cpp:42, 122-128; pathTracerPrograms.cu:727)
-    for field, bad in (("maxDepth", 0), ("maxDepth", 29), ("samplesPerPixel", 0)):
+    for field, bad in (("maxDepth", 0), ("maxDepth", 29), ("samplesPerPixel", 0), ("width", 0), ("height", 70000)):
         q = copy_params(state.params)
         setattr(q, field, bad)
         assert L.pt_launch(state.context, C.byref(q)) != 0
