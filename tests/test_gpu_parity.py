@@ -485,3 +485,41 @@ def test_trackball_orbit_changes_the_view(tmp_path):
         imgs.append(np.asarray(Image.open(out).convert("RGB")).astype(np.float32))
     assert imgs[0].shape == (96, 128, 3) and imgs[0].mean() > 10 and imgs[1].mean() > 10
     assert np.abs(imgs[0] - imgs[1]).mean() > 5.0
+
+
+def test_lifetime_and_streams():
+    """Contexts, scenes and launches can be created, replaced and destroyed repeatedly without leaking device
+    memory; launches enqueued on a caller-provided stream (torch's) are ordered with the caller's work."""
+    import torch
+    L = _native.hip()
+    torch.cuda.init()
+    free0, _ = torch.cuda.mem_get_info()
+    obj = pt.TinyObjWrapper(SCENE_FULL)
+    for it in range(6):
+        state = pt.PathTracerState()
+        pt.createDeviceContext(state, 0)
+        for _ in range(3):
+            pt.buildTheAccelarationStructure(state, obj)          # replaces the previous scene
+        p = make_params(64, 48, 4, 4, True, True)
+        p.handle = state.params.handle
+        acc = torch.zeros((48, 64, 4), dtype=torch.float32, device="cuda")
+        fb = torch.zeros((48, 64, 4), dtype=torch.uint8, device="cuda")
+        p.accumulationBuffer, p.frameBuffer = acc.data_ptr(), fb.data_ptr()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            assert L.pt_set_stream(state.context, C.c_void_p(side.cuda_stream)) == 0
+            acc.fill_(7.0)                                            # on `side`, before the launch
+            assert L.pt_launch(state.context, C.byref(p)) == 0
+            total = acc[..., 3].sum()                                 # on `side`, after the launch
+        side.synchronize()
+        assert float(total) == 64 * 48                              # alpha 1 everywhere: the fill did not overtake the launch
+        assert L.pt_set_stream(state.context, None) == 0
+        stale = copy_params(p); stale.handle = 12345
+        assert L.pt_launch(state.context, C.byref(stale)) != 0 and b"stale" in L.pt_last_error(state.context)
+        state.params.accumulationBuffer = None
+        L.pt_destroy(state.context)
+        state.context = None
+        del acc, fb
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, "device memory leaked: %d MiB" % ((free0 - free1) >> 20)
