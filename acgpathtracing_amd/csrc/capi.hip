@@ -409,6 +409,42 @@ PT_API int pt_trace_any(pt_ctx* c, const float* rays, size_t n, uint8_t* hit_out
     });
 }
 
+PT_API int pt_bench_traversal(pt_ctx* c, const float* rays, size_t n, int repeats, float* t_out, uint32_t* prim_out, float* ms_out)
+{
+    if (!c || !rays || !t_out || !prim_out || !ms_out || n == 0 || n > 0x7FFFFFFFull || repeats < 1) return fail(c, "pt_bench_traversal: bad argument");
+    CK(c, hipSetDevice(c->device));
+    float* d_rays = nullptr; float* d_t = nullptr; uint32_t* d_p = nullptr; uint32_t* d_head = nullptr;
+    int bpc = 0;
+    hipError_t e = ptd::trace_stream_occupancy(c->stack_entries, &bpc);
+    if (e == hipSuccess && bpc < 1) e = hipErrorInvalidValue;
+    if (e == hipSuccess) e = hipMalloc((void**)&d_rays, n * 32);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_t, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_p, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_head, 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rays, rays, n * 32, hipMemcpyHostToDevice, c->stream);
+    float best = 1e30f;
+    const ptd::DeviceScene sc = device_scene(c);
+    for (int r = 0; r < repeats && e == hipSuccess; r++) {
+        e = hipMemsetAsync(d_head, 0, 4, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(c->ev0, c->stream);
+        if (e == hipSuccess) e = ptd::launch_trace_stream(sc, c->stack_entries, d_rays, (uint32_t)n, d_head, d_t, d_p, (uint32_t)(c->n_cus * bpc), c->stream);
+        if (e == hipSuccess) e = hipEventRecord(c->ev1, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        float ms = 0.0f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        if (ms < best) best = ms;
+    }
+    if (e == hipSuccess) e = hipMemcpy(t_out, d_t, n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(prim_out, d_p, n * 4, hipMemcpyDeviceToHost);
+    if (d_rays) (void)hipFree(d_rays);
+    if (d_t) (void)hipFree(d_t);
+    if (d_p) (void)hipFree(d_p);
+    if (d_head) (void)hipFree(d_head);
+    if (e != hipSuccess) return fail(c, std::string("pt_bench_traversal: ") + hipGetErrorString(e));
+    *ms_out = best;
+    return 0;
+}
+
 PT_API int pt_read_morton(pt_ctx* c, uint32_t* codes_sorted, uint32_t* prims_sorted)
 {
     if (!c || !codes_sorted || !prims_sorted) return fail(c, "pt_read_morton: null argument");

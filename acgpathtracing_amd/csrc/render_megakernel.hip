@@ -567,6 +567,139 @@ k_trace_any(const DeviceScene sc, uint32_t stack_entries, const float* __restric
     if (active) hit_out[i] = f ? 1 : 0;
 }
 
+// ---- traversal-ceiling diagnostic -----------------------------------------------------------------
+// A ray-stream kernel with nothing but the BVH loop: persistent waves pull rays (origin, direction,
+// tmin, tmax; tmax < 0 marks an any-hit ray with |tmax|) from a global array, a lane that finishes
+// writes its result and takes the next ray inside the loop (ballot-prefix hand-out from a wave-local
+// grant).  No path state, no shading: few registers, full occupancy, lanes (almost) never idle.  It
+// answers one question — how fast could traversal alone go on this scene and ray mix — and is
+// bit-checked against pt_trace_closest / pt_trace_any.
+template <int FETCH_K, int LEAF_K>
+__global__ void __launch_bounds__(256)
+k_trace_stream(const DeviceScene sc, uint32_t stack_entries, const float4* __restrict__ rays, uint32_t n,
+               uint32_t* __restrict__ head, float* __restrict__ t_out, uint32_t* __restrict__ prim_out)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    LaneStack st;
+    st.base = lds_dyn + (threadIdx.x >> 6) * (stack_entries * 64u) + lane;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t res_first = 0, res_count = 0;      // wave-local grant
+    bool drained = false;
+    // ray in flight
+    uint32_t rid = 0xFFFFFFFFu;
+    f3 ro = mk(0.0f), rd = mk(0.0f, 0.0f, 1.0f), rinv = mk(1.0f);
+    float rtmin = 0.0f, rtmax = 0.0f, best_t = 0.0f;
+    int best_slot = -1; uint32_t best_prim = 0xFFFFFFFFu;
+    int node = kSentinel, sp = 0, tos = kSentinel;
+    bool any_ray = false, any_hit = false;
+    for (;;) {
+        // retire finished rays, fetch new ones
+        const bool idle_lane = node == kSentinel;
+        unsigned long long idle = __ballot(idle_lane);
+        const unsigned long long busy = ~idle;
+        if (idle != 0ull && (__popcll(idle) >= FETCH_K || busy == 0ull)) {
+            if (idle_lane && rid != 0xFFFFFFFFu) {
+                if (any_ray) { t_out[rid] = any_hit ? 1.0f : 0.0f; prim_out[rid] = any_hit ? 1u : 0u; }
+                else { t_out[rid] = best_slot >= 0 ? best_t : -1.0f; prim_out[rid] = best_prim; }
+                rid = 0xFFFFFFFFu;
+            }
+            while (idle != 0ull && !(drained && res_count == 0u)) {
+                if (res_count == 0u) {
+                    const uint32_t leader = (uint32_t)__ffsll((long long)idle) - 1u;
+                    uint32_t base = 0;
+                    if (lane == leader) base = atomicAdd(head, 256u);
+                    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+                    res_first = base;
+                    res_count = base < n ? min(256u, n - base) : 0u;
+                    if (res_count < 256u) drained = true;
+                    if (res_count == 0u) break;
+                }
+                const uint32_t want = (uint32_t)__popcll(idle);
+                const uint32_t take = want < res_count ? want : res_count;
+                const uint32_t rank = (uint32_t)__popcll(idle & below);
+                if (idle_lane && rid == 0xFFFFFFFFu && rank < take) {
+                    rid = res_first + rank;
+                    const float4 a = rays[2ull * rid], b = rays[2ull * rid + 1];
+                    ro = mk(a.x, a.y, a.z); rd = mk(a.w, b.x, b.y); rtmin = b.z;
+                    any_ray = b.w < 0.0f; rtmax = fabsf(b.w);
+                    rinv = mk(fast_rcp(rd.x), fast_rcp(rd.y), fast_rcp(rd.z));
+                    best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu; any_hit = false;
+                    node = sc.n_tris ? 0 : kSentinel; sp = 0;
+                }
+                res_first += take; res_count -= take;
+                idle = __ballot(rid == 0xFFFFFFFFu);
+            }
+            if (__ballot(node != kSentinel) == 0ull) {
+                if (__ballot(rid != 0xFFFFFFFFu) == 0ull && drained && res_count == 0u) break;   // nothing in flight, nothing left
+                continue;       // rays of an empty scene retire on the next turn
+            }
+        }
+        // one traversal step
+        if (node >= 0 && node != kSentinel) {
+            const BvhNode* np = sc.nodes + node;
+            const float4 a = np->a, b = np->b, c = np->c;
+            const int4 ch = np->d;
+            float x0 = (a.x - ro.x) * rinv.x, x1 = (a.w - ro.x) * rinv.x;
+            float y0 = (a.y - ro.y) * rinv.y, y1 = (b.x - ro.y) * rinv.y;
+            float z0 = (a.z - ro.z) * rinv.z, z1 = (b.y - ro.z) * rinv.z;
+            float n0 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), rtmin));
+            float f0 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1)) * kFarWiden;
+            float u0 = (b.z - ro.x) * rinv.x, u1 = (c.y - ro.x) * rinv.x;
+            float v0 = (b.w - ro.y) * rinv.y, v1 = (c.z - ro.y) * rinv.y;
+            float w0 = (c.x - ro.z) * rinv.z, w1 = (c.w - ro.z) * rinv.z;
+            float n1 = fmaxf(fmaxf(fminf(u0, u1), fminf(v0, v1)), fmaxf(fminf(w0, w1), rtmin));
+            float f1 = fminf(fminf(fmaxf(u0, u1), fmaxf(v0, v1)), fmaxf(w0, w1)) * kFarWiden;
+            f0 = fminf(f0, best_t);
+            f1 = fminf(f1, best_t);
+            const bool h0 = n0 <= f0, h1 = n1 <= f1;
+            const bool first0 = n0 <= n1;
+            const int near_c = (h0 && (first0 || !h1)) ? ch.x : ch.y;
+            const int far_c = first0 ? ch.y : ch.x;
+            if (h0 && h1) { st.push(sp, tos); tos = far_c; sp++; }
+            if (h0 || h1) node = near_c;
+            else { node = sp ? tos : kSentinel; sp = sp ? sp - 1 : 0; tos = st.pop(sp); }
+        }
+        const bool at_leaf = node < 0;
+        const unsigned long long lm = __ballot(at_leaf);
+        if (lm != 0ull && (__popcll(lm) >= LEAF_K || __ballot(node >= 0 && node != kSentinel) == 0ull)) {
+            if (at_leaf) {
+                const int slot = ~node;
+                const TriRecord* tp = sc.tris + slot;
+                const float4 r0 = tp->r0, r1 = tp->r1, r2 = tp->r2;
+                float t;
+                const bool ok = tri_test_lazy(ro, rd, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), rtmin, rtmax, t);
+                const uint32_t prim = __float_as_uint(r2.y);
+                bool stop = false;
+                if (ok) {
+                    if (any_ray) { any_hit = true; stop = true; }
+                    else if (t < best_t || (t == best_t && prim < best_prim)) { best_t = t; best_slot = slot; best_prim = prim; }
+                }
+                node = (stop || sp == 0) ? kSentinel : tos;
+                sp = sp ? sp - 1 : 0;
+                tos = st.pop(sp);
+            }
+        }
+    }
+}
+
+hipError_t launch_trace_stream(const DeviceScene& sc, uint32_t stack_entries, const float* d_rays, uint32_t n, uint32_t* d_head,
+                               float* d_t, uint32_t* d_prim, uint32_t grid_blocks, hipStream_t stream)
+{
+    const size_t lds = (size_t)4 * stack_entries * 256u;
+    hipError_t e = hipFuncSetAttribute((const void*)k_trace_stream<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    k_trace_stream<8, 8><<<grid_blocks, 256, lds, stream>>>(sc, stack_entries, (const float4*)d_rays, n, d_head, d_t, d_prim);
+    return hipGetLastError();
+}
+
+hipError_t trace_stream_occupancy(uint32_t stack_entries, int* blocks_per_cu)
+{
+    const size_t lds = (size_t)4 * stack_entries * 256u;
+    hipError_t e = hipFuncSetAttribute((const void*)k_trace_stream<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, (const void*)k_trace_stream<8, 8>, 256, lds);
+}
+
 // ---- host-side launchers ------------------------------------------------------------------
 typedef void (*RenderKernel)(const RenderArgs);
 

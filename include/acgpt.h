@@ -199,6 +199,11 @@ int pt_get_stats(pt_ctx* ctx, pt_stats* out);
  * 651-684).                                                                    */
 int pt_trace_closest(pt_ctx* ctx, const float* rays, size_t n, float* t_out, uint32_t* prim_out);
 int pt_trace_any(pt_ctx* ctx, const float* rays, size_t n, uint8_t* hit_out);
+/* Diagnostic: pure-traversal throughput.  Streams n HOST rays (same 8-float records; tmax < 0 marks an
+ * any-hit ray of length |tmax|) through a persistent kernel that contains nothing but the BVH loop, `repeats`
+ * times, and reports the fastest kernel time.  Results: closest rays as pt_trace_closest; any-hit rays give
+ * t_out = prim_out = 1 when occluded, 0 otherwise.  Not used by the render path.                        */
+int pt_bench_traversal(pt_ctx* ctx, const float* rays, size_t n, int repeats, float* t_out, uint32_t* prim_out, float* ms_out);
 /* Sorted (morton, triangle) pairs of the last build, HOST outputs of n_tris. */
 int pt_read_morton(pt_ctx* ctx, uint32_t* codes_sorted, uint32_t* prims_sorted);
 

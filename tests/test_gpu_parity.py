@@ -522,4 +522,29 @@ def test_lifetime_and_streams():
         del acc, fb
     torch.cuda.synchronize(); torch.cuda.empty_cache()
     free1, _ = torch.cuda.mem_get_info()
-    assert free0 - free1 < 64 << 20, "device memory leaked: %d MiB" % ((free0 - free1) >> 20)
+    assert free0 - free1 < 64 << 20, "device memory leaked: %d MiB" % ((free0 - free1) >> 20)@pytest.mark.gpu
+def test_ray_stream_kernel_bit_exact(full):
+    """pt_bench_traversal (persistent ray-stream kernel, closest and any-hit rays mixed in one launch,
+    more rays than resident lanes so the in-loop refill runs) against brute force."""
+    state, obj, sc = full
+    v, idx = scene_arrays(obj)
+    closest = np.concatenate([random_rays(300000, 41), adversarial_rays(v, idx, 42)])
+    anyr = random_rays(250000, 43, tmin=0.01, tmax=250.0)
+    rays = np.concatenate([closest, anyr]).astype(np.float32)
+    rays[closest.shape[0]:, 7] *= -1.0                      # negative tmax marks an any-hit ray
+    perm = np.random.default_rng(44).permutation(rays.shape[0])
+    rays = np.ascontiguousarray(rays[perm])
+    n = rays.shape[0]
+    t = np.zeros(n, np.float32); prim = np.zeros(n, np.uint32); ms = C.c_float()
+    L = _native.hip()
+    assert L.pt_bench_traversal(state.context, rays.ctypes.data, n, 2, t.ctypes.data, prim.ctypes.data, C.byref(ms)) == 0
+    is_c = rays[:, 7] > 0
+    t_ref, prim_ref = sc.trace_closest(np.ascontiguousarray(rays[is_c]), use_bvh=False)
+    assert np.array_equal(prim[is_c], prim_ref) and np.array_equal(t[is_c].view(np.uint32), t_ref.view(np.uint32))
+    ar = np.ascontiguousarray(rays[~is_c]); ar[:, 7] *= -1.0
+    assert np.array_equal(prim[~is_c] != 0, sc.trace_any(ar, use_bvh=False) != 0)
+    assert ms.value > 0
+    assert L.pt_bench_traversal(state.context, rays.ctypes.data, 0, 1, t.ctypes.data, prim.ctypes.data, C.byref(ms)) != 0   # empty stream: refused
+
+
+
