@@ -14,7 +14,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 HOST = os.path.join(PKG, "host")
 
-HIP_SOURCES = ["capi.hip", "lbvh_build.hip", "render_megakernel.hip"]
+HIP_SOURCES = ["capi.hip", "lbvh_build.hip", "wide_bvh.hip", "render_megakernel.hip"]
 HIP_HEADERS = ["pt_device.h", "lbvh_build.h", "render_megakernel.h"]
 HOST_SOURCES = ["host_capi.cpp", "TinyObjWrapper.cpp", "Camera.cpp", "Trackball.cpp", "ImageIO.cpp"]
 

@@ -53,7 +53,8 @@ class Stats(C.Structure):
 class BvhInfo(C.Structure):
     _fields_ = [("n_tris", C.c_uint32), ("n_nodes", C.c_uint32), ("max_depth", C.c_uint32), ("stack_entries", C.c_uint32),
                 ("scene_lo", C.c_float * 3), ("scene_hi", C.c_float * 3), ("build_ms", C.c_float),
-                ("node_bytes", C.c_uint32), ("tri_bytes", C.c_uint32)]
+                ("node_bytes", C.c_uint32), ("tri_bytes", C.c_uint32),
+                ("wide_nodes", C.c_uint32), ("wide_depth", C.c_uint32), ("wide_bytes", C.c_uint32), ("wide_ms", C.c_float)]
 
 
 assert C.sizeof(PathTraceParams) == 168
@@ -108,7 +109,7 @@ def hip():
     L.pt_get_stats.argtypes = [vp, C.POINTER(Stats)]; L.pt_get_stats.restype = C.c_int
     L.pt_trace_closest.argtypes = [vp, vp, sz, vp, vp]; L.pt_trace_closest.restype = C.c_int
     L.pt_trace_any.argtypes = [vp, vp, sz, vp]; L.pt_trace_any.restype = C.c_int
-    L.pt_bench_traversal.argtypes = [vp, vp, sz, C.c_int, vp, vp, C.POINTER(C.c_float)]; L.pt_bench_traversal.restype = C.c_int
+    L.pt_bench_traversal.argtypes = [vp, vp, sz, C.c_int, C.c_int, vp, vp, C.POINTER(C.c_float), vp]; L.pt_bench_traversal.restype = C.c_int
     L.pt_read_morton.argtypes = [vp, vp, vp]; L.pt_read_morton.restype = C.c_int
     L.pt_device_malloc.argtypes = [vp, C.POINTER(vp), sz]; L.pt_device_malloc.restype = C.c_int
     L.pt_device_free.argtypes = [vp, vp]; L.pt_device_free.restype = C.c_int

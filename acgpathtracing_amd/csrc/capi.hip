@@ -137,8 +137,10 @@ PT_API int pt_set_scene(pt_ctx* c, const float* verts_xyzw, size_t n_verts, cons
         CK(c, hipMemcpy(c->d_mats, mats, n_mats * sizeof(pt_material), hipMemcpyHostToDevice));
     }
     c->n_mats = (uint32_t)n_mats;
-    // one push per internal node on a root-to-leaf path, at most
+    // dwords per lane: one push per internal node on a root-to-leaf path at most (two-child tree), or one
+    // 8-byte group per level (four-wide tree); every kernel variant gets the larger of the two
     uint32_t need = c->bvh.max_depth + 1u;
+    if (need < 2u * (c->bvh.wide_depth + 1u)) need = 2u * (c->bvh.wide_depth + 1u);
     if (need < 8u) need = 8u;
     need = (need + 3u) & ~3u;
     if (need > 128u) return fail(c, "pt_set_scene: BVH deeper than the traversal stack supports");
@@ -163,6 +165,10 @@ PT_API int pt_get_bvh_info(pt_ctx* c, pt_bvh_info* out)
     out->build_ms = c->bvh.build_ms;
     out->node_bytes = c->bvh.n_nodes * (uint32_t)sizeof(ptd::BvhNode);
     out->tri_bytes = c->bvh.n_tris * (uint32_t)sizeof(ptd::TriRecord);
+    out->wide_nodes = c->bvh.n_wnodes;
+    out->wide_depth = c->bvh.wide_depth;
+    out->wide_bytes = c->bvh.n_wrecs * 48u;
+    out->wide_ms = c->bvh.wide_ms;
     return 0;
 }
 
@@ -218,7 +224,7 @@ PT_API int pt_set_stream(pt_ctx* c, void* s)
 static ptd::DeviceScene device_scene(pt_ctx* c)
 {
     ptd::DeviceScene sc;
-    sc.nodes = c->bvh.nodes; sc.qnodes = c->bvh.qnodes; sc.grid = c->bvh.grid; sc.tris = c->bvh.tris; sc.mats = c->d_mats;
+    sc.nodes = c->bvh.nodes; sc.qnodes = c->bvh.qnodes; sc.grid = c->bvh.grid; sc.tris = c->bvh.tris; sc.wrecs = c->bvh.wrecs; sc.mats = c->d_mats;
     sc.n_tris = c->bvh.n_tris; sc.n_mats = c->n_mats;
     return sc;
 }
@@ -409,13 +415,16 @@ PT_API int pt_trace_any(pt_ctx* c, const float* rays, size_t n, uint8_t* hit_out
     });
 }
 
-PT_API int pt_bench_traversal(pt_ctx* c, const float* rays, size_t n, int repeats, float* t_out, uint32_t* prim_out, float* ms_out)
+PT_API int pt_bench_traversal(pt_ctx* c, const float* rays, size_t n, int repeats, int node_format, float* t_out, uint32_t* prim_out, float* ms_out,
+                              uint64_t* counters_out)
 {
-    if (!c || !rays || !t_out || !prim_out || !ms_out || n == 0 || n > 0x7FFFFFFFull || repeats < 1) return fail(c, "pt_bench_traversal: bad argument");
+    if (!c || !rays || !t_out || !prim_out || !ms_out || n == 0 || n > 0x7FFFFFFFull || repeats < 1 || node_format < 0 || node_format > 1)
+        return fail(c, "pt_bench_traversal: bad argument");
+    const uint32_t entries = node_format ? (c->bvh.wide_depth + 1u) : c->stack_entries;
     CK(c, hipSetDevice(c->device));
     float* d_rays = nullptr; float* d_t = nullptr; uint32_t* d_p = nullptr; uint32_t* d_head = nullptr;
     int bpc = 0;
-    hipError_t e = ptd::trace_stream_occupancy(c->stack_entries, &bpc);
+    hipError_t e = ptd::trace_stream_occupancy(node_format, entries, &bpc);
     if (e == hipSuccess && bpc < 1) e = hipErrorInvalidValue;
     if (e == hipSuccess) e = hipMalloc((void**)&d_rays, n * 32);
     if (e == hipSuccess) e = hipMalloc((void**)&d_t, n * 4);
@@ -426,8 +435,9 @@ PT_API int pt_bench_traversal(pt_ctx* c, const float* rays, size_t n, int repeat
     const ptd::DeviceScene sc = device_scene(c);
     for (int r = 0; r < repeats && e == hipSuccess; r++) {
         e = hipMemsetAsync(d_head, 0, 4, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream);
         if (e == hipSuccess) e = hipEventRecord(c->ev0, c->stream);
-        if (e == hipSuccess) e = ptd::launch_trace_stream(sc, c->stack_entries, d_rays, (uint32_t)n, d_head, d_t, d_p, (uint32_t)(c->n_cus * bpc), c->stream);
+        if (e == hipSuccess) e = ptd::launch_trace_stream(node_format, sc, entries, d_rays, (uint32_t)n, d_head, d_t, d_p, c->d_counters, (uint32_t)(c->n_cus * bpc), c->stream);
         if (e == hipSuccess) e = hipEventRecord(c->ev1, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         float ms = 0.0f;
@@ -436,6 +446,7 @@ PT_API int pt_bench_traversal(pt_ctx* c, const float* rays, size_t n, int repeat
     }
     if (e == hipSuccess) e = hipMemcpy(t_out, d_t, n * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(prim_out, d_p, n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && counters_out) e = hipMemcpy(counters_out, c->d_counters, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost);
     if (d_rays) (void)hipFree(d_rays);
     if (d_t) (void)hipFree(d_t);
     if (d_p) (void)hipFree(d_p);

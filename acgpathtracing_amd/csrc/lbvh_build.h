@@ -13,6 +13,9 @@ struct LbvhResult {
     QNode*     qnodes = nullptr;       // device, n_nodes (16-bit grid boxes, 32 B)
     QGrid      grid = {};              // world -> grid transform of qnodes
     TriRecord* tris = nullptr;         // device, n_tris, Morton order
+    uint4*     wrecs = nullptr;        // device, n_wrecs x 48 B: four-wide nodes + triangles (wide_bvh.hip)
+    uint32_t   n_wrecs = 0, n_wnodes = 0, wide_depth = 0;
+    float      wide_ms = 0.0f;         // host collapse + upload
     uint32_t*  keys_sorted = nullptr;  // device, n_tris
     uint32_t*  vals_sorted = nullptr;  // device, n_tris (original triangle index per slot)
     uint32_t   n_tris = 0, n_nodes = 0, max_depth = 0;
@@ -28,5 +31,8 @@ bool build_lbvh(const float* h_verts_xyzw, size_t n_verts, const uint32_t* h_idx
                 const uint32_t* h_mat_ids, int mode, hipStream_t stream, LbvhResult& out, std::string& err);
 
 void free_lbvh(LbvhResult& r);
+
+// Collapse the two-child tree into the four-wide, 8-bit-quantised record array (wide_bvh.hip).
+bool build_wide4(LbvhResult& r, hipStream_t stream, std::string& err);
 
 }  // namespace ptd

@@ -453,6 +453,7 @@ void free_lbvh(LbvhResult& r)
     if (r.nodes) (void)hipFree(r.nodes);
     if (r.qnodes) (void)hipFree(r.qnodes);
     if (r.tris) (void)hipFree(r.tris);
+    if (r.wrecs) (void)hipFree(r.wrecs);
     if (r.keys_sorted) (void)hipFree(r.keys_sorted);
     if (r.vals_sorted) (void)hipFree(r.vals_sorted);
     r = LbvhResult();
@@ -581,6 +582,11 @@ bool build_lbvh(const float* h_verts_xyzw, size_t n_verts, const uint32_t* h_idx
     out.mode = mode;
     if (n_tris == 0) return true;
     if (!build_impl(h_verts_xyzw, n_verts, h_idx, (uint32_t)n_tris, h_mat_ids, mode, stream, out, err)) {
+        (void)hipStreamSynchronize(stream);
+        free_lbvh(out);
+        return false;
+    }
+    if (!build_wide4(out, stream, err)) {
         (void)hipStreamSynchronize(stream);
         free_lbvh(out);
         return false;

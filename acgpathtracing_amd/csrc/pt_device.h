@@ -56,6 +56,7 @@ struct DeviceScene {
     const QNode*       qnodes;
     QGrid              grid;
     const TriRecord*   tris;
+    const uint4*       wrecs;     // four-wide tree: 48-byte records, wide nodes and triangles in one array (wide_bvh.hip)
     const pt_material* mats;
     uint32_t n_tris;
     uint32_t n_mats;
@@ -63,6 +64,10 @@ struct DeviceScene {
 
 constexpr int   kSentinel  = 0x7FFFFFFF;   // stack bottom marker (never a valid node index)
 constexpr float kFarWiden  = 1.000001f;    // conservative slab test (Ize 2013) incl. the 1-ulp v_rcp_f32 direction
+// Pruning against the best hit so far uses best_t * kTieWiden: a triangle whose computed distance ties with
+// (or is a few ulps below) the current best must still be reached, and its box entry distance and its
+// Moeller-Trumbore distance round independently.  The triangle test itself is exact about (tmin, tmax).
+constexpr float kTieWiden  = 1.00002f;
 constexpr float kPIf       = 3.14159265358979323846f;
 
 // ------------------------------------------------------------------ float3 ----
@@ -200,13 +205,13 @@ __device__ __forceinline__ bool traverse(const DeviceScene& sc, const LaneStack&
             float z0 = (a.z - o.z) * iz, z1 = (b.y - o.z) * iz;
             float n0 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
             float f0 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1)) * kFarWiden;
-            f0 = fminf(f0, hit.t);
+            f0 = fminf(f0, hit.t * kTieWiden);
             float u0 = (b.z - o.x) * ix, u1 = (c.y - o.x) * ix;
             float v0 = (b.w - o.y) * iy, v1 = (c.z - o.y) * iy;
             float w0 = (c.x - o.z) * iz, w1 = (c.w - o.z) * iz;
             float n1 = fmaxf(fmaxf(fminf(u0, u1), fminf(v0, v1)), fmaxf(fminf(w0, w1), tmin));
             float f1 = fminf(fminf(fmaxf(u0, u1), fmaxf(v0, v1)), fmaxf(w0, w1)) * kFarWiden;
-            f1 = fminf(f1, hit.t);
+            f1 = fminf(f1, hit.t * kTieWiden);
             const bool h0 = n0 <= f0, h1 = n1 <= f1;
             if (h0 && h1) {
                 const bool first0 = n0 <= n1;
@@ -236,6 +241,60 @@ __device__ __forceinline__ bool traverse(const DeviceScene& sc, const LaneStack&
         }
     }
     return found;
+}
+
+// ------------------------------------------------------------ four-wide tree ----
+// Stack of {base, list} groups, one per tree level at most (see wide_bvh.hip); entry-major like LaneStack.
+struct LaneStack2 {
+    uint2* base;      // &lds[wave_region + lane]
+    __device__ __forceinline__ void push(int sp, uint32_t b, uint32_t l) const { base[sp * 64] = make_uint2(b, l); }
+    __device__ __forceinline__ uint2 pop(int sp) const { return base[sp * 64]; }
+};
+
+__device__ __forceinline__ float ubyte_f(uint32_t v, int k) { return (float)((v >> (8 * k)) & 0xFFu); }   // v_cvt_f32_ubyteN
+
+// Visit wide node `node`: test its (up to four) child boxes, return the hit children near-to-far as a list of
+// nibbles (8 | leaf << 2 | k; 0 terminates) and the record index of child 0.
+// Plane distance = byte * (scale / d) + (origin - o) / d: the scale is a power of two, so the only roundings
+// are those of (origin - o) / d and the fma itself; wide_bvh.hip's margin covers them.  A NaN (0 * inf for an
+// axis-parallel ray) drops that plane from the max / min, which only widens the test.
+__device__ __forceinline__ uint32_t wide_visit(const uint4* __restrict__ R, int node, const f3& ro, const f3& rinv,
+                                               float rtmin, float best_t, uint32_t& base)
+{
+    const uint4* rp = R + 3u * (uint32_t)node;
+    const uint4 h0 = rp[0], h1 = rp[1], h2 = rp[2];
+    const uint32_t em = h0.w;
+    const float ax = __uint_as_float((em & 0xFFu) << 23) * rinv.x;
+    const float ay = __uint_as_float(((em >> 8) & 0xFFu) << 23) * rinv.y;
+    const float az = __uint_as_float(((em >> 16) & 0xFFu) << 23) * rinv.z;
+    const float bx = (__uint_as_float(h0.x) - ro.x) * rinv.x;
+    const float by = (__uint_as_float(h0.y) - ro.y) * rinv.y;
+    const float bz = (__uint_as_float(h0.z) - ro.z) * rinv.z;
+    const uint32_t n_inner = (em >> 24) & 7u, n_child = em >> 27;
+    const float prune_t = best_t * kTieWiden;
+    base = h1.x;
+    // lo planes: h1.z h1.w h2.x ; hi planes: h2.y h2.z h2.w ; near = lo for a positive direction
+    const bool ngx = rinv.x < 0.0f, ngy = rinv.y < 0.0f, ngz = rinv.z < 0.0f;
+    const uint32_t qnx = ngx ? h2.y : h1.z, qfx = ngx ? h1.z : h2.y;
+    const uint32_t qny = ngy ? h2.z : h1.w, qfy = ngy ? h1.w : h2.z;
+    const uint32_t qnz = ngz ? h2.w : h2.x, qfz = ngz ? h2.x : h2.w;
+    uint32_t key[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float tnx = __builtin_fmaf(ubyte_f(qnx, k), ax, bx), tfx = __builtin_fmaf(ubyte_f(qfx, k), ax, bx);
+        const float tny = __builtin_fmaf(ubyte_f(qny, k), ay, by), tfy = __builtin_fmaf(ubyte_f(qfy, k), ay, by);
+        const float tnz = __builtin_fmaf(ubyte_f(qnz, k), az, bz), tfz = __builtin_fmaf(ubyte_f(qfz, k), az, bz);
+        const float nn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, rtmin));
+        const float ff = fminf(fminf(fminf(tfx, tfy), tfz) * kFarWiden, prune_t);
+        const bool hit = (nn <= ff) && ((uint32_t)k < n_child);
+        const uint32_t tag = 8u | ((uint32_t)k >= n_inner ? 4u : 0u) | (uint32_t)k;
+        key[k] = hit ? ((__float_as_uint(nn) & ~15u) | tag) : 0xFFFFFFF0u;
+    }
+    // sorting network (ascending); misses carry a zero nibble and sort last
+#define PT_CAS(i, j) { const uint32_t lo_ = min(key[i], key[j]), hi_ = max(key[i], key[j]); key[i] = lo_; key[j] = hi_; }
+    PT_CAS(0, 1) PT_CAS(2, 3) PT_CAS(0, 2) PT_CAS(1, 3) PT_CAS(1, 2)
+#undef PT_CAS
+    return (key[0] & 15u) | ((key[1] & 15u) << 4) | ((key[2] & 15u) << 8) | ((key[3] & 15u) << 12);
 }
 
 }  // namespace ptd

@@ -42,9 +42,9 @@ hipError_t launch_render(int variant, const RenderArgs& args, uint32_t grid_bloc
 hipError_t launch_items(const RenderArgs& args, hipStream_t stream);
 hipError_t launch_finalize(const RenderArgs& args, hipStream_t stream);
 hipError_t launch_resolve(const float4* accum, uint32_t* fb, uint32_t n, hipStream_t stream);
-hipError_t launch_trace_stream(const DeviceScene& sc, uint32_t stack_entries, const float* d_rays, uint32_t n, uint32_t* d_head,
-                               float* d_t, uint32_t* d_prim, uint32_t grid_blocks, hipStream_t stream);
-hipError_t trace_stream_occupancy(uint32_t stack_entries, int* blocks_per_cu);
+hipError_t launch_trace_stream(int fmt, const DeviceScene& sc, uint32_t stack_entries, const float* d_rays, uint32_t n, uint32_t* d_head,
+                               float* d_t, uint32_t* d_prim, unsigned long long* d_counters, uint32_t grid_blocks, hipStream_t stream);
+hipError_t trace_stream_occupancy(int fmt, uint32_t stack_entries, int* blocks_per_cu);
 hipError_t launch_trace_closest(const DeviceScene& sc, uint32_t stack_entries, const float* d_rays, uint32_t n,
                                 float* d_t, uint32_t* d_prim, hipStream_t stream);
 hipError_t launch_trace_any(const DeviceScene& sc, uint32_t stack_entries, const float* d_rays, uint32_t n,

@@ -259,6 +259,8 @@ k_render(const RenderArgs A)
 //           1 = 16-bit grid boxes, 32-byte nodes in global memory (2 loads per visit)
 //           2 = the same 32-byte nodes staged into LDS by each workgroup (scenes whose node array
 //               fits beside the lane stacks; 1024-thread workgroups so one copy serves 16 waves)
+//           3 = four-wide tree, 8-bit child boxes, 48-byte records shared with the triangles (wide_bvh.hip):
+//               3 loads per visit and about half the visits; the stack holds {base, child list} groups
 // DIAG (timing experiments only, never a product variant): 1 = 12 extra dependent VALU per inner
 // step, 2 = two extra 16-byte loads per inner step.
 // INNER: 0 = stack entirely in LDS, nested branches; 1 = stack top cached in a register (the LDS read of
@@ -271,7 +273,10 @@ k_render_pw(const RenderArgs A)
     const uint32_t wave = threadIdx.x >> 6;
     LaneStack st;
     st.base = lds_dyn + wave * (A.stack_entries * 64u) + lane;
-    const DeviceScene sc = A.scene;
+    LaneStack2 st2;                                   // NODE_FMT 3: the same LDS region as stack_entries / 2 groups
+    st2.base = (uint2*)(lds_dyn + wave * (A.stack_entries * 64u)) + lane;
+    DeviceScene sc = A.scene;
+    if (NODE_FMT == 3) sc.tris = (const TriRecord*)A.scene.wrecs;      // triangles live in the record array
     const uint2* lds_nodes = (const uint2*)(lds_dyn + (THREADS / 64) * (A.stack_entries * 64u));
     if (NODE_FMT == 2) {
         uint4* dst = (uint4*)(lds_dyn + (THREADS / 64) * (A.stack_entries * 64u));
@@ -299,6 +304,7 @@ k_render_pw(const RenderArgs A)
     float rtmin = 0.0f, rtmax = 0.0f, best_t = 0.0f;
     int best_slot = -1; uint32_t best_prim = 0xFFFFFFFFu;
     int node = kSentinel, sp = 0, tos = kSentinel;
+    uint32_t cur_base = 0, cur_list = 0;              // NODE_FMT 3: innermost group of pending children
     bool shadow_ray = false, shadow_hit = false;
     // held while the shadow ray is in flight
     Pending pd; pd.nxt_org = mk(0.0f); pd.nxt_dir = mk(0.0f, 0.0f, 1.0f); pd.radiance = mk(0.0f); pd.weight = 0.0f; pd.done = true;
@@ -324,12 +330,12 @@ k_render_pw(const RenderArgs A)
                 lp.result += emission;                                // :760 (before the radiance term)
                 if (want_shadow) {
                     ro = P; rd = L; rinv = mk(fast_rcp(L.x), fast_rcp(L.y), fast_rcp(L.z));
-                    if (NODE_FMT != 0) {
+                    if (NODE_FMT == 1 || NODE_FMT == 2) {
                         gro = mk((ro.x - G.ox) * G.icx, (ro.y - G.oy) * G.icy, (ro.z - G.oz) * G.icz);
                         rinv = mk(G.cx * rinv.x, G.cy * rinv.y, G.cz * rinv.z);
                     }
                     rtmin = 0.01f; rtmax = Ldist - 0.01f; best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu;
-                    node = root; sp = 0; shadow_ray = true; shadow_hit = false; started_shadow = true;
+                    node = root; sp = 0; cur_list = 0u; shadow_ray = true; shadow_hit = false; started_shadow = true;
                 } else {
                     segment_done = true;
                 }
@@ -374,12 +380,12 @@ k_render_pw(const RenderArgs A)
         }
         if (start_radiance) {                                         // traceRadiance :750-757
             rinv = mk(fast_rcp(rd.x), fast_rcp(rd.y), fast_rcp(rd.z));
-            if (NODE_FMT != 0) {
+            if (NODE_FMT == 1 || NODE_FMT == 2) {
                 gro = mk((ro.x - G.ox) * G.icx, (ro.y - G.oy) * G.icy, (ro.z - G.oz) * G.icz);
                 rinv = mk(G.cx * rinv.x, G.cy * rinv.y, G.cz * rinv.z);
             }
             rtmin = 0.01f; rtmax = 1e16f; best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu;
-            node = root; sp = 0; shadow_ray = false;
+            node = root; sp = 0; cur_list = 0u; shadow_ray = false;
         }
         n_radiance += (unsigned long long)__popcll(__ballot(start_radiance));
 
@@ -390,6 +396,47 @@ k_render_pw(const RenderArgs A)
             if (am == 0ull) break;
             if (__popcll(__ballot(!act && lp.alive)) >= SHADE_K) break;
             if (STATS) { n_steps += 1; n_lane_steps += (unsigned long long)__popcll(am); }
+            if (NODE_FMT == 3) {
+                const bool at_inner = act && node >= 0;
+                const bool leaf_lane = node < 0;
+                const unsigned long long lmask = __ballot(leaf_lane);
+                const bool leaf_round = lmask != 0ull && (LEAF_K <= 1 || __popcll(lmask) >= LEAF_K || __ballot(at_inner) == 0ull);
+                bool next = false;
+                if (at_inner) {
+                    uint32_t base;
+                    const uint32_t list = wide_visit(sc.wrecs, node, ro, rinv, rtmin, best_t, base);
+                    if (list != 0u) {
+                        if (cur_list != 0u) { st2.push(sp, cur_base, cur_list); sp++; }
+                        cur_base = base; cur_list = list;
+                    }
+                    next = true;
+                }
+                if (leaf_round && leaf_lane) {
+                    const int slot = ~node;
+                    const TriRecord* tp = sc.tris + slot;
+                    const float4 r0 = tp->r0, r1 = tp->r1, r2 = tp->r2;
+                    float t;
+                    const bool ok = tri_test_lazy(ro, rd, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), rtmin, rtmax, t);
+                    const uint32_t prim = __float_as_uint(r2.y);
+                    if (ok) {
+                        if (shadow_ray) { shadow_hit = true; cur_list = 0u; sp = 0; }
+                        else if (t < best_t || (t == best_t && prim < best_prim)) { best_t = t; best_slot = slot; best_prim = prim; }
+                    }
+                    next = true;
+                }
+                if (next) {
+                    if (cur_list == 0u && sp > 0) { sp--; const uint2 g = st2.pop(sp); cur_base = g.x; cur_list = g.y; }
+                    if (cur_list != 0u) {
+                        const uint32_t nib = cur_list & 15u;
+                        cur_list >>= 4;
+                        const int idx = (int)(cur_base + (nib & 3u));
+                        node = (nib & 4u) ? ~idx : idx;
+                    } else {
+                        node = kSentinel;
+                    }
+                }
+                continue;
+            }
             if (act && node >= 0) {
                 float n0, f0, n1, f1; int c0, c1;
                 if (NODE_FMT == 0) {
@@ -443,8 +490,8 @@ k_render_pw(const RenderArgs A)
                                  : "=&v"(e0), "=&v"(e1) : "v"(xp) : "memory");
                     asm volatile("" :: "v"(e0), "v"(e1));
                 }
-                f0 = fminf(f0, best_t);
-                f1 = fminf(f1, best_t);
+                f0 = fminf(f0, best_t * kTieWiden);
+                f1 = fminf(f1, best_t * kTieWiden);
                 const bool h0 = n0 <= f0, h1 = n1 <= f1;
                 if (INNER == 0) {
                     if (h0 && h1) {
@@ -577,7 +624,8 @@ k_trace_any(const DeviceScene sc, uint32_t stack_entries, const float* __restric
 template <int FETCH_K, int LEAF_K>
 __global__ void __launch_bounds__(256)
 k_trace_stream(const DeviceScene sc, uint32_t stack_entries, const float4* __restrict__ rays, uint32_t n,
-               uint32_t* __restrict__ head, float* __restrict__ t_out, uint32_t* __restrict__ prim_out)
+               uint32_t* __restrict__ head, float* __restrict__ t_out, uint32_t* __restrict__ prim_out,
+               unsigned long long* __restrict__ counters)
 {
     const uint32_t lane = threadIdx.x & 63u;
     LaneStack st;
@@ -592,6 +640,7 @@ k_trace_stream(const DeviceScene sc, uint32_t stack_entries, const float4* __res
     int best_slot = -1; uint32_t best_prim = 0xFFFFFFFFu;
     int node = kSentinel, sp = 0, tos = kSentinel;
     bool any_ray = false, any_hit = false;
+    unsigned long long n_iter = 0, n_visit = 0, n_tri = 0, n_vround = 0, n_lround = 0;
     for (;;) {
         // retire finished rays, fetch new ones
         const bool idle_lane = node == kSentinel;
@@ -635,6 +684,7 @@ k_trace_stream(const DeviceScene sc, uint32_t stack_entries, const float4* __res
             }
         }
         // one traversal step
+        { const unsigned long long vm = __ballot(node >= 0 && node != kSentinel); n_iter++; n_visit += (unsigned long long)__popcll(vm); n_vround += vm ? 1u : 0u; }
         if (node >= 0 && node != kSentinel) {
             const BvhNode* np = sc.nodes + node;
             const float4 a = np->a, b = np->b, c = np->c;
@@ -649,8 +699,8 @@ k_trace_stream(const DeviceScene sc, uint32_t stack_entries, const float4* __res
             float w0 = (c.x - ro.z) * rinv.z, w1 = (c.w - ro.z) * rinv.z;
             float n1 = fmaxf(fmaxf(fminf(u0, u1), fminf(v0, v1)), fmaxf(fminf(w0, w1), rtmin));
             float f1 = fminf(fminf(fmaxf(u0, u1), fmaxf(v0, v1)), fmaxf(w0, w1)) * kFarWiden;
-            f0 = fminf(f0, best_t);
-            f1 = fminf(f1, best_t);
+            f0 = fminf(f0, best_t * kTieWiden);
+            f1 = fminf(f1, best_t * kTieWiden);
             const bool h0 = n0 <= f0, h1 = n1 <= f1;
             const bool first0 = n0 <= n1;
             const int near_c = (h0 && (first0 || !h1)) ? ch.x : ch.y;
@@ -662,6 +712,7 @@ k_trace_stream(const DeviceScene sc, uint32_t stack_entries, const float4* __res
         const bool at_leaf = node < 0;
         const unsigned long long lm = __ballot(at_leaf);
         if (lm != 0ull && (__popcll(lm) >= LEAF_K || __ballot(node >= 0 && node != kSentinel) == 0ull)) {
+            n_tri += (unsigned long long)__popcll(lm); n_lround++;
             if (at_leaf) {
                 const int slot = ~node;
                 const TriRecord* tp = sc.tris + slot;
@@ -680,24 +731,145 @@ k_trace_stream(const DeviceScene sc, uint32_t stack_entries, const float4* __res
             }
         }
     }
+    if (lane == 0) {
+        atomicAdd(&counters[0], n_iter); atomicAdd(&counters[1], n_visit); atomicAdd(&counters[2], n_tri);
+        atomicAdd(&counters[3], n_vround); atomicAdd(&counters[4], n_lround);
+    }
 }
 
-hipError_t launch_trace_stream(const DeviceScene& sc, uint32_t stack_entries, const float* d_rays, uint32_t n, uint32_t* d_head,
-                               float* d_t, uint32_t* d_prim, uint32_t grid_blocks, hipStream_t stream)
+// The same ray-stream kernel over the four-wide tree (wide_bvh.hip): a lane's current work item is a wide
+// node (>= 0), a triangle record (~index) or nothing; the children still to do at each level wait as
+// {base, near-to-far nibble list} groups, the innermost in registers, the rest on the LDS stack.
+template <int FETCH_K, int LEAF_K>
+__global__ void __launch_bounds__(256)
+k_trace_stream_w4(const DeviceScene sc, uint32_t stack_entries, const float4* __restrict__ rays, uint32_t n,
+                  uint32_t* __restrict__ head, float* __restrict__ t_out, uint32_t* __restrict__ prim_out,
+               unsigned long long* __restrict__ counters)
 {
-    const size_t lds = (size_t)4 * stack_entries * 256u;
-    hipError_t e = hipFuncSetAttribute((const void*)k_trace_stream<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const uint32_t lane = threadIdx.x & 63u;
+    LaneStack2 st;
+    st.base = (uint2*)lds_dyn + (threadIdx.x >> 6) * (stack_entries * 64u) + lane;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const uint4* __restrict__ R = sc.wrecs;
+    const TriRecord* __restrict__ T = (const TriRecord*)sc.wrecs;
+    uint32_t res_first = 0, res_count = 0;
+    bool drained = false;
+    uint32_t rid = 0xFFFFFFFFu;
+    f3 ro = mk(0.0f), rd = mk(0.0f, 0.0f, 1.0f), rinv = mk(1.0f);
+    float rtmin = 0.0f, rtmax = 0.0f, best_t = 0.0f;
+    int best_slot = -1; uint32_t best_prim = 0xFFFFFFFFu;
+    int node = kSentinel, sp = 0;
+    uint32_t cur_base = 0, cur_list = 0;
+    bool any_ray = false, any_hit = false;
+    unsigned long long n_iter = 0, n_visit = 0, n_tri = 0, n_vround = 0, n_lround = 0;
+    for (;;) {
+        const bool idle_lane = node == kSentinel;
+        unsigned long long idle = __ballot(idle_lane);
+        const unsigned long long busy = ~idle;
+        if (idle != 0ull && (__popcll(idle) >= FETCH_K || busy == 0ull)) {
+            if (idle_lane && rid != 0xFFFFFFFFu) {
+                if (any_ray) { t_out[rid] = any_hit ? 1.0f : 0.0f; prim_out[rid] = any_hit ? 1u : 0u; }
+                else { t_out[rid] = best_slot >= 0 ? best_t : -1.0f; prim_out[rid] = best_prim; }
+                rid = 0xFFFFFFFFu;
+            }
+            while (idle != 0ull && !(drained && res_count == 0u)) {
+                if (res_count == 0u) {
+                    const uint32_t leader = (uint32_t)__ffsll((long long)idle) - 1u;
+                    uint32_t base = 0;
+                    if (lane == leader) base = atomicAdd(head, 256u);
+                    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+                    res_first = base;
+                    res_count = base < n ? min(256u, n - base) : 0u;
+                    if (res_count < 256u) drained = true;
+                    if (res_count == 0u) break;
+                }
+                const uint32_t want = (uint32_t)__popcll(idle);
+                const uint32_t take = want < res_count ? want : res_count;
+                const uint32_t rank = (uint32_t)__popcll(idle & below);
+                if (idle_lane && rid == 0xFFFFFFFFu && rank < take) {
+                    rid = res_first + rank;
+                    const float4 a = rays[2ull * rid], b = rays[2ull * rid + 1];
+                    ro = mk(a.x, a.y, a.z); rd = mk(a.w, b.x, b.y); rtmin = b.z;
+                    any_ray = b.w < 0.0f; rtmax = fabsf(b.w);
+                    rinv = mk(fast_rcp(rd.x), fast_rcp(rd.y), fast_rcp(rd.z));
+                    best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu; any_hit = false;
+                    node = sc.n_tris ? 0 : kSentinel; sp = 0; cur_list = 0;
+                }
+                res_first += take; res_count -= take;
+                idle = __ballot(rid == 0xFFFFFFFFu);
+            }
+            if (__ballot(node != kSentinel) == 0ull) {
+                if (__ballot(rid != 0xFFFFFFFFu) == 0ull && drained && res_count == 0u) break;
+                continue;
+            }
+        }
+        const bool at_leaf = node < 0;
+        const bool at_inner = node >= 0 && node != kSentinel;
+        const unsigned long long lm = __ballot(at_leaf);
+        const bool leaf_round = lm != 0ull && (__popcll(lm) >= LEAF_K || __ballot(at_inner) == 0ull);
+        { const unsigned long long vm = __ballot(at_inner); n_iter++; n_visit += (unsigned long long)__popcll(vm); n_vround += vm ? 1u : 0u;
+          if (leaf_round) { n_tri += (unsigned long long)__popcll(lm); n_lround++; } }
+        bool next = false;
+        if (at_inner) {
+            uint32_t base;
+            const uint32_t list = wide_visit(R, node, ro, rinv, rtmin, best_t, base);
+            if (list != 0u) {
+                if (cur_list != 0u) { st.push(sp, cur_base, cur_list); sp++; }
+                cur_base = base; cur_list = list;
+            }
+            next = true;
+        }
+        if (leaf_round && at_leaf) {
+            const int slot = ~node;
+            const TriRecord* tp = T + slot;
+            const float4 r0 = tp->r0, r1 = tp->r1, r2 = tp->r2;
+            float t;
+            const bool ok = tri_test_lazy(ro, rd, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), rtmin, rtmax, t);
+            const uint32_t prim = __float_as_uint(r2.y);
+            if (ok) {
+                if (any_ray) { any_hit = true; cur_list = 0u; sp = 0; }
+                else if (t < best_t || (t == best_t && prim < best_prim)) { best_t = t; best_slot = slot; best_prim = prim; }
+            }
+            next = true;
+        }
+        if (next) {
+            if (cur_list == 0u && sp > 0) { sp--; const uint2 g = st.pop(sp); cur_base = g.x; cur_list = g.y; }
+            if (cur_list != 0u) {
+                const uint32_t nib = cur_list & 15u;
+                cur_list >>= 4;
+                const int idx = (int)(cur_base + (nib & 3u));
+                node = (nib & 4u) ? ~idx : idx;
+            } else {
+                node = kSentinel;
+            }
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&counters[0], n_iter); atomicAdd(&counters[1], n_visit); atomicAdd(&counters[2], n_tri);
+        atomicAdd(&counters[3], n_vround); atomicAdd(&counters[4], n_lround);
+    }
+}
+
+// fmt 0: two-child fp32 tree (stack_entries dwords per lane); fmt 1: four-wide tree (stack_entries 8-byte groups)
+hipError_t launch_trace_stream(int fmt, const DeviceScene& sc, uint32_t stack_entries, const float* d_rays, uint32_t n, uint32_t* d_head,
+                               float* d_t, uint32_t* d_prim, unsigned long long* d_counters, uint32_t grid_blocks, hipStream_t stream)
+{
+    const size_t lds = (size_t)(fmt ? 8 : 4) * stack_entries * 256u;
+    const void* k = fmt ? (const void*)k_trace_stream_w4<8, 8> : (const void*)k_trace_stream<8, 8>;
+    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    k_trace_stream<8, 8><<<grid_blocks, 256, lds, stream>>>(sc, stack_entries, (const float4*)d_rays, n, d_head, d_t, d_prim);
+    if (fmt) k_trace_stream_w4<8, 8><<<grid_blocks, 256, lds, stream>>>(sc, stack_entries, (const float4*)d_rays, n, d_head, d_t, d_prim, d_counters);
+    else k_trace_stream<8, 8><<<grid_blocks, 256, lds, stream>>>(sc, stack_entries, (const float4*)d_rays, n, d_head, d_t, d_prim, d_counters);
     return hipGetLastError();
 }
 
-hipError_t trace_stream_occupancy(uint32_t stack_entries, int* blocks_per_cu)
+hipError_t trace_stream_occupancy(int fmt, uint32_t stack_entries, int* blocks_per_cu)
 {
-    const size_t lds = (size_t)4 * stack_entries * 256u;
-    hipError_t e = hipFuncSetAttribute((const void*)k_trace_stream<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = (size_t)(fmt ? 8 : 4) * stack_entries * 256u;
+    const void* k = fmt ? (const void*)k_trace_stream_w4<8, 8> : (const void*)k_trace_stream<8, 8>;
+    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, (const void*)k_trace_stream<8, 8>, 256, lds);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k, 256, lds);
 }
 
 // ---- host-side launchers ------------------------------------------------------------------
@@ -719,6 +891,11 @@ static const VariantDesc kVariants[] = {
     {k_render_pw<48, 8, 0, 256, 4, false, 1, 1>, 256, 0, "DIAG +12 VALU per inner step"},
     {k_render_pw<48, 8, 0, 256, 4, false, 2, 1>, 256, 0, "DIAG +2 loads per inner step"},
     {k_render_pw<48, 8, 0, 256, 4, false, 3, 1>, 256, 0, "DIAG hardware sin/cos, algebraic acos (wrong bits, timing only)"},
+    {k_render_pw<48, 8, 3, 256, 4, false, 0, 1>, 256, 3, "pw K48 L8 four-wide 8-bit nodes w4"},
+    {k_render_pw<48, 8, 3, 256, 4, true, 0, 1>, 256, 3, "four-wide + scheduler stats"},
+    {k_render_pw<48, 16, 3, 256, 4, false, 0, 1>, 256, 3, "pw K48 L16 four-wide"},
+    {k_render_pw<40, 8, 3, 256, 4, false, 0, 1>, 256, 3, "pw K40 L8 four-wide"},
+    {k_render_pw<48, 8, 3, 256, 5, false, 0, 1>, 256, 3, "pw K48 L8 four-wide w5"},
 };
 int render_variant_count() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
 const char* render_variant_name(int v) { return (v >= 0 && v < render_variant_count()) ? kVariants[v].name : "?"; }

@@ -115,6 +115,10 @@ typedef struct pt_bvh_info {
     float    build_ms;        /* morton + sort + hierarchy + refit, device ms */
     uint32_t node_bytes;      /* bytes of the traversal node array            */
     uint32_t tri_bytes;       /* bytes of the leaf triangle array             */
+    uint32_t wide_nodes;      /* four-wide tree: nodes                        */
+    uint32_t wide_depth;      /* four-wide tree: levels                       */
+    uint32_t wide_bytes;      /* four-wide tree: record array (nodes + triangles, 48 B each) */
+    float    wide_ms;         /* collapse of the two-child tree, host ms      */
 } pt_bvh_info;
 
 /* ---- lifetime -------------------------------------------------------------
@@ -201,9 +205,13 @@ int pt_trace_closest(pt_ctx* ctx, const float* rays, size_t n, float* t_out, uin
 int pt_trace_any(pt_ctx* ctx, const float* rays, size_t n, uint8_t* hit_out);
 /* Diagnostic: pure-traversal throughput.  Streams n HOST rays (same 8-float records; tmax < 0 marks an
  * any-hit ray of length |tmax|) through a persistent kernel that contains nothing but the BVH loop, `repeats`
- * times, and reports the fastest kernel time.  Results: closest rays as pt_trace_closest; any-hit rays give
- * t_out = prim_out = 1 when occluded, 0 otherwise.  Not used by the render path.                        */
-int pt_bench_traversal(pt_ctx* ctx, const float* rays, size_t n, int repeats, float* t_out, uint32_t* prim_out, float* ms_out);
+ * times, and reports the fastest kernel time.  node_format 0: two-child fp32 tree; 1: four-wide 8-bit tree.
+ * Results: closest rays as pt_trace_closest; any-hit rays give t_out = prim_out = 1 when occluded, 0
+ * otherwise.  counters_out (may be NULL): 5 values of the last repeat — loop iterations summed over waves,
+ * node visits summed over lanes, triangle tests summed over lanes, iterations with a node visit, iterations
+ * with a triangle round.  Not used by the render path.                                                   */
+int pt_bench_traversal(pt_ctx* ctx, const float* rays, size_t n, int repeats, int node_format, float* t_out, uint32_t* prim_out, float* ms_out,
+                       uint64_t* counters_out);
 /* Sorted (morton, triangle) pairs of the last build, HOST outputs of n_tris. */
 int pt_read_morton(pt_ctx* ctx, uint32_t* codes_sorted, uint32_t* prims_sorted);
 

@@ -379,7 +379,9 @@ static inline void closest_bvh(const Scene& sc, const f3& o, const f3& d, float 
     uint32_t stack[128]; int sp = 0; stack[sp++] = 0;
     while (sp) {
         const BNode& n = sc.nodes[stack[--sp]];
-        if (!box_test(n, o, inv, tmin, h.t)) continue;    /* t0 <= best keeps equal-t candidates */
+        /* widened: a triangle whose distance ties with the best so far must still be reached (its box entry
+         * distance and its Moeller-Trumbore distance round independently) */
+        if (!box_test(n, o, inv, tmin, h.t * 1.00002f)) continue;
         if (n.count) {
             for (uint32_t i = n.first; i < n.first + n.count; i++) {
                 uint32_t p = sc.order[i]; float t;

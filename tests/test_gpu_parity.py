@@ -535,16 +535,18 @@ def test_ray_stream_kernel_bit_exact(full):
     perm = np.random.default_rng(44).permutation(rays.shape[0])
     rays = np.ascontiguousarray(rays[perm])
     n = rays.shape[0]
-    t = np.zeros(n, np.float32); prim = np.zeros(n, np.uint32); ms = C.c_float()
     L = _native.hip()
-    assert L.pt_bench_traversal(state.context, rays.ctypes.data, n, 2, t.ctypes.data, prim.ctypes.data, C.byref(ms)) == 0
     is_c = rays[:, 7] > 0
     t_ref, prim_ref = sc.trace_closest(np.ascontiguousarray(rays[is_c]), use_bvh=False)
-    assert np.array_equal(prim[is_c], prim_ref) and np.array_equal(t[is_c].view(np.uint32), t_ref.view(np.uint32))
     ar = np.ascontiguousarray(rays[~is_c]); ar[:, 7] *= -1.0
-    assert np.array_equal(prim[~is_c] != 0, sc.trace_any(ar, use_bvh=False) != 0)
-    assert ms.value > 0
-    assert L.pt_bench_traversal(state.context, rays.ctypes.data, 0, 1, t.ctypes.data, prim.ctypes.data, C.byref(ms)) != 0   # empty stream: refused
+    any_ref = sc.trace_any(ar, use_bvh=False) != 0
+    for fmt in (0, 1):                                       # two-child fp32 tree, four-wide 8-bit tree
+        t = np.zeros(n, np.float32); prim = np.zeros(n, np.uint32); ms = C.c_float()
+        assert L.pt_bench_traversal(state.context, rays.ctypes.data, n, 2, fmt, t.ctypes.data, prim.ctypes.data, C.byref(ms), None) == 0
+        assert np.array_equal(prim[is_c], prim_ref) and np.array_equal(t[is_c].view(np.uint32), t_ref.view(np.uint32)), fmt
+        assert np.array_equal(prim[~is_c] != 0, any_ref), fmt
+        assert ms.value > 0
+    assert L.pt_bench_traversal(state.context, rays.ctypes.data, 0, 1, 0, t.ctypes.data, prim.ctypes.data, C.byref(ms), None) != 0   # empty stream: refused
 
 
 

@@ -1,0 +1,177 @@
+// ubench_valu.hip — SIMD cycles per wave64 vector instruction on gfx950, for the instruction kinds the BVH
+// loop is made of, at 1, 2, 4 and 8 waves per SIMD.  Each kernel runs ITERS x 64 instances of one instruction on
+// 8 independent registers per lane (no dependent-issue stall beyond what the hardware imposes).
+// Build: hipcc --offload-arch=gfx950 -O3 tools/ubench_valu.hip -o tools/ubench_valu
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+#define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define BODY(NAME, ASM) \
+__global__ void __launch_bounds__(256) NAME(int iters, float* out) { \
+    float r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7; \
+    float a = 1.0001f, b = 0.5f; uint32_t m = 0x0F0F0F0Fu; \
+    for (int i = 0; i < iters; i++) { \
+        _Pragma("unroll") for (int k = 0; k < 8; k++) { \
+            asm volatile(ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7) \
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "v"(m) : "vcc"); \
+        } \
+    } \
+    if (r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 == 12345.678f) out[0] = r0; \
+}
+#define A_ADD(n)   "v_add_f32 %" #n ", %" #n ", %8\n"
+#define A_MUL(n)   "v_mul_f32 %" #n ", %" #n ", %8\n"
+#define A_FMA(n)   "v_fma_f32 %" #n ", %" #n ", %8, %9\n"
+#define A_MAX(n)   "v_max_f32 %" #n ", %" #n ", %8\n"
+#define A_MAX3(n)  "v_max3_f32 %" #n ", %" #n ", %8, %9\n"
+#define A_AND(n)   "v_and_b32 %" #n ", %" #n ", %10\n"
+#define A_ADDU(n)  "v_add_u32 %" #n ", %" #n ", %10\n"
+#define A_SHL(n)   "v_lshlrev_b32 %" #n ", 1, %" #n "\n"
+#define A_MINU(n)  "v_min_u32 %" #n ", %" #n ", %10\n"
+#define A_CVTB(n)  "v_cvt_f32_ubyte1 %" #n ", %" #n "\n"
+#define A_CVTU(n)  "v_cvt_f32_u32 %" #n ", %" #n "\n"
+#define A_CND(n)   "v_cndmask_b32 %" #n ", %" #n ", %8, vcc\n"
+#define A_CMP(n)   "v_cmp_lt_f32 vcc, %" #n ", %8\n"
+#define A_CMPS(n)  "v_cmp_lt_f32 s[20:21], %" #n ", %8\n"
+#define A_RCP(n)   "v_rcp_f32 %" #n ", %" #n "\n"
+#define A_MOV(n)   "v_mov_b32 %" #n ", %8\n"
+#define A_LSHLOR(n) "v_lshl_or_b32 %" #n ", %" #n ", 4, %10\n"
+#define A_ANDOR(n) "v_and_or_b32 %" #n ", %" #n ", %10, %10\n"
+#define A_BFI(n)   "v_bfi_b32 %" #n ", %10, %" #n ", %8\n"
+#define A_MIN3(n)  "v_min3_f32 %" #n ", %" #n ", %8, %9\n"
+#define A_SUB(n)   "v_sub_f32 %" #n ", %" #n ", %8\n"
+#define A_XOR(n)   "v_xor_b32 %" #n ", %" #n ", %10\n"
+#define A_MAD24(n) "v_mad_u32_u24 %" #n ", %" #n ", %10, %10\n"
+#define A_PKFMA(n) "v_pk_fma_f32 %" #n ", %" #n ", %8, %9\n"
+BODY(k_add, A_ADD) BODY(k_mul, A_MUL) BODY(k_fma, A_FMA) BODY(k_max, A_MAX) BODY(k_max3, A_MAX3) BODY(k_and, A_AND)
+BODY(k_addu, A_ADDU) BODY(k_shl, A_SHL) BODY(k_minu, A_MINU) BODY(k_cvtb, A_CVTB) BODY(k_cvtu, A_CVTU) BODY(k_cnd, A_CND)
+BODY(k_bfi, A_BFI) BODY(k_min3, A_MIN3) BODY(k_sub, A_SUB) BODY(k_xor, A_XOR) BODY(k_mad24, A_MAD24)
+BODY(k_cmp, A_CMP) BODY(k_rcp, A_RCP) BODY(k_mov, A_MOV) BODY(k_lshlor, A_LSHLOR) BODY(k_andor, A_ANDOR)
+
+__global__ void __launch_bounds__(256) k_cmps(int iters, float* out) {
+    float r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7;
+    float a = 1.0001f, b = 0.5f; uint32_t m = 0;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            asm volatile(A_CMPS(0) A_CMPS(1) A_CMPS(2) A_CMPS(3) A_CMPS(4) A_CMPS(5) A_CMPS(6) A_CMPS(7)
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "v"(m) : "s20", "s21");
+    }
+    if (r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 == 12345.678f) out[0] = r0;
+}
+// v_cndmask variants: mask in an initialised SGPR pair; vcc written by a v_cmp right before each select; v_bfi as a select
+__global__ void __launch_bounds__(256) k_cnd_s(int iters, float* out) {
+    float r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7;
+    float a = 1.0001f;
+    asm volatile("s_mov_b64 s[20:21], 0x55555555\n" ::: "s20", "s21");
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            asm volatile("v_cndmask_b32 %0, %0, %8, s[20:21]\nv_cndmask_b32 %1, %1, %8, s[20:21]\nv_cndmask_b32 %2, %2, %8, s[20:21]\nv_cndmask_b32 %3, %3, %8, s[20:21]\n"
+                         "v_cndmask_b32 %4, %4, %8, s[20:21]\nv_cndmask_b32 %5, %5, %8, s[20:21]\nv_cndmask_b32 %6, %6, %8, s[20:21]\nv_cndmask_b32 %7, %7, %8, s[20:21]\n"
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a) : "s20", "s21");
+    }
+    if (r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 == 12345.678f) out[0] = r0;
+}
+__global__ void __launch_bounds__(256) k_cnd_init(int iters, float* out) {
+    float r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7;
+    float a = 1.0001f;
+    for (int i = 0; i < iters; i++) {
+        asm volatile("v_cmp_lt_f32 vcc, %0, %1\n" :: "v"(r0), "v"(a) : "vcc");
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            asm volatile("v_cndmask_b32 %0, %0, %8, vcc\nv_cndmask_b32 %1, %1, %8, vcc\nv_cndmask_b32 %2, %2, %8, vcc\nv_cndmask_b32 %3, %3, %8, vcc\n"
+                         "v_cndmask_b32 %4, %4, %8, vcc\nv_cndmask_b32 %5, %5, %8, vcc\nv_cndmask_b32 %6, %6, %8, vcc\nv_cndmask_b32 %7, %7, %8, vcc\n"
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a) : );
+    }
+    if (r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 == 12345.678f) out[0] = r0;
+}
+__global__ void __launch_bounds__(256) k_cmp_cnd(int iters, float* out) {     // counts PAIRS
+    float r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7;
+    float a = 1.0001f;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            asm volatile("v_cmp_lt_f32 vcc, %0, %8\nv_cndmask_b32 %0, %0, %8, vcc\nv_cmp_lt_f32 vcc, %1, %8\nv_cndmask_b32 %1, %1, %8, vcc\n"
+                         "v_cmp_lt_f32 vcc, %2, %8\nv_cndmask_b32 %2, %2, %8, vcc\nv_cmp_lt_f32 vcc, %3, %8\nv_cndmask_b32 %3, %3, %8, vcc\n"
+                         "v_cmp_lt_f32 vcc, %4, %8\nv_cndmask_b32 %4, %4, %8, vcc\nv_cmp_lt_f32 vcc, %5, %8\nv_cndmask_b32 %5, %5, %8, vcc\n"
+                         "v_cmp_lt_f32 vcc, %6, %8\nv_cndmask_b32 %6, %6, %8, vcc\nv_cmp_lt_f32 vcc, %7, %8\nv_cndmask_b32 %7, %7, %8, vcc\n"
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a) : "vcc");
+    }
+    if (r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 == 12345.678f) out[0] = r0;
+}
+// one compare feeding four selects (a swap of two pairs): counts GROUPS of 5 instructions
+__global__ void __launch_bounds__(256) k_cmp_cnd4(int iters, float* out) {
+    float r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7;
+    float a = 1.0001f;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            asm volatile("v_cmp_lt_f32 vcc, %0, %8\nv_cndmask_b32 %0, %0, %8, vcc\nv_cndmask_b32 %1, %1, %8, vcc\nv_cndmask_b32 %2, %2, %8, vcc\nv_cndmask_b32 %3, %3, %8, vcc\n"
+                         "v_cmp_lt_f32 vcc, %4, %8\nv_cndmask_b32 %4, %4, %8, vcc\nv_cndmask_b32 %5, %5, %8, vcc\nv_cndmask_b32 %6, %6, %8, vcc\nv_cndmask_b32 %7, %7, %8, vcc\n"
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a) : "vcc");
+    }
+    if (r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 == 12345.678f) out[0] = r0;
+}
+// same with the mask in an SGPR pair
+__global__ void __launch_bounds__(256) k_cmps_cnd4(int iters, float* out) {
+    float r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7;
+    float a = 1.0001f;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            asm volatile("v_cmp_lt_f32 s[20:21], %0, %8\nv_cndmask_b32 %0, %0, %8, s[20:21]\nv_cndmask_b32 %1, %1, %8, s[20:21]\nv_cndmask_b32 %2, %2, %8, s[20:21]\nv_cndmask_b32 %3, %3, %8, s[20:21]\n"
+                         "v_cmp_lt_f32 s[22:23], %4, %8\nv_cndmask_b32 %4, %4, %8, s[22:23]\nv_cndmask_b32 %5, %5, %8, s[22:23]\nv_cndmask_b32 %6, %6, %8, s[22:23]\nv_cndmask_b32 %7, %7, %8, s[22:23]\n"
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a) : "s20", "s21", "s22", "s23");
+    }
+    if (r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 == 12345.678f) out[0] = r0;
+}
+// scalar: s_and_b64 / s_bcnt1 chain next to nothing else
+__global__ void __launch_bounds__(256) k_salu(int iters, float* out) {
+    unsigned long long x = 0x123456789ull + blockIdx.x; uint32_t c = 0;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 64; k++) asm volatile("s_and_b64 %0, %0, exec\n" : "+s"(x) : : "scc");
+    }
+    if (x == 0x1234567 && c == 7) out[0] = 1.0f;
+}
+
+typedef void (*Kern)(int, float*);
+struct Desc { const char* name; Kern k; };
+
+int main()
+{
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount; const double ghz = prop.clockRate / 1e6;
+    printf("device %s, %d CUs, %.2f GHz\n", prop.gcnArchName, cus, ghz);
+    float* d; CK(hipMalloc(&d, 4));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const Desc ks[] = {{"v_add_f32", k_add}, {"v_mul_f32", k_mul}, {"v_fma_f32", k_fma}, {"v_max_f32", k_max}, {"v_max3_f32", k_max3},
+                       {"v_and_b32", k_and}, {"v_add_u32", k_addu}, {"v_lshlrev_b32", k_shl}, {"v_min_u32", k_minu}, {"v_cvt_f32_ubyte1", k_cvtb},
+                       {"v_cvt_f32_u32", k_cvtu}, {"v_cndmask_b32 (vcc)", k_cnd}, {"v_cmp_lt_f32 vcc", k_cmp}, {"v_cmp_lt_f32 sgpr pair", k_cmps},
+                       {"v_cndmask (sgpr pair, set)", k_cnd_s}, {"v_cndmask (vcc from v_cmp)", k_cnd_init}, {"v_cmp + v_cndmask PAIR", k_cmp_cnd},
+                       {"1 v_cmp vcc + 4 v_cndmask (x0.2)", k_cmp_cnd4}, {"1 v_cmp sgpr + 4 v_cndmask (x0.2)", k_cmps_cnd4},
+                       {"v_bfi_b32", k_bfi}, {"v_min3_f32", k_min3}, {"v_sub_f32", k_sub}, {"v_xor_b32", k_xor}, {"v_mad_u32_u24", k_mad24}, {"v_rcp_f32", k_rcp}, {"v_mov_b32", k_mov}, {"v_lshl_or_b32", k_lshlor}, {"v_and_or_b32", k_andor}, {"s_and_b64 (scalar)", k_salu}};
+    const int iters = 2000;
+    printf("%-26s %10s %10s %10s %10s   SIMD cycles per wave-instruction\n", "instruction", "1 w/SIMD", "2 w/SIMD", "4 w/SIMD", "8 w/SIMD");
+    for (const Desc& kd : ks) {
+        printf("%-34s", kd.name);
+        for (int wps : {1, 2, 4, 8}) {
+            const int blocks = cus * wps;      // 256 threads = 4 waves = one per SIMD
+            kd.k<<<blocks, 256>>>(10, d);
+            CK(hipDeviceSynchronize());
+            float best = 1e30f;
+            for (int r = 0; r < 3; r++) {
+                CK(hipEventRecord(e0));
+                kd.k<<<blocks, 256>>>(iters, d);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+            }
+            const double instr_per_simd = (double)iters * 64.0 * wps;
+            printf(" %10.2f", best * 1e-3 * ghz * 1e9 / instr_per_simd);
+        }
+        printf("\n");
+    }
+    return 0;
+}
