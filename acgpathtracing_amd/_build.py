@@ -19,7 +19,7 @@ HIP_HEADERS = ["pt_device.h", "lbvh_build.h", "render_megakernel.h"]
 HOST_SOURCES = ["host_capi.cpp", "TinyObjWrapper.cpp", "Camera.cpp", "Trackball.cpp", "ImageIO.cpp"]
 
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden", "-std=c++17"]
-HOST_FLAGS = ["-O2", "-std=c++14", "-fPIC", "-shared", "-ffp-contract=off", "-fvisibility=hidden"]
+HOST_FLAGS = ["-O2", "-std=c++14", "-fPIC", "-shared", "-ffp-contract=off", "-fvisibility=hidden", "-pthread"]
 
 
 def _stale(target, deps):

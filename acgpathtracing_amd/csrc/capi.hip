@@ -115,6 +115,31 @@ PT_API void pt_destroy(pt_ctx* c)
     delete c;
 }
 
+// dwords per lane: one push per internal node on a root-to-leaf path at most (two-child tree), or one
+// 8-byte group per level (four-wide tree, if built); every kernel variant gets the larger of the two
+static int size_stack(pt_ctx* c)
+{
+    uint32_t need = c->bvh.max_depth + 1u;
+    if (c->bvh.wrecs && need < 2u * (c->bvh.wide_depth + 1u)) need = 2u * (c->bvh.wide_depth + 1u);
+    if (need < 8u) need = 8u;
+    need = (need + 3u) & ~3u;
+    if (need > 128u) return fail(c, "pt_set_scene: BVH deeper than the traversal stack supports");
+    c->stack_entries = need;
+    CK(c, ptd::render_occupancy(c->variant, c->stack_entries, c->bvh.n_nodes, &c->blocks_per_cu));
+    if (c->blocks_per_cu < 1) return fail(c, "render kernel does not fit on a CU with this stack size");
+    return 0;
+}
+
+// The four-wide tree is built on first use (a kernel variant or diagnostic that walks it): its host-side
+// collapse is not part of the default scene set-up.
+static int ensure_wide(pt_ctx* c)
+{
+    if (c->bvh.wrecs || c->bvh.n_tris == 0) return 0;
+    std::string err;
+    if (!ptd::build_wide4(c->bvh, c->stream, err)) return fail(c, err);
+    return size_stack(c);
+}
+
 PT_API int pt_set_scene(pt_ctx* c, const float* verts_xyzw, size_t n_verts, const uint32_t* idx, size_t n_tris,
                         const uint32_t* mat_ids, const pt_material* mats, size_t n_mats)
 {
@@ -137,16 +162,8 @@ PT_API int pt_set_scene(pt_ctx* c, const float* verts_xyzw, size_t n_verts, cons
         CK(c, hipMemcpy(c->d_mats, mats, n_mats * sizeof(pt_material), hipMemcpyHostToDevice));
     }
     c->n_mats = (uint32_t)n_mats;
-    // dwords per lane: one push per internal node on a root-to-leaf path at most (two-child tree), or one
-    // 8-byte group per level (four-wide tree); every kernel variant gets the larger of the two
-    uint32_t need = c->bvh.max_depth + 1u;
-    if (need < 2u * (c->bvh.wide_depth + 1u)) need = 2u * (c->bvh.wide_depth + 1u);
-    if (need < 8u) need = 8u;
-    need = (need + 3u) & ~3u;
-    if (need > 128u) return fail(c, "pt_set_scene: BVH deeper than the traversal stack supports");
-    c->stack_entries = need;
-    CK(c, ptd::render_occupancy(c->variant, c->stack_entries, c->bvh.n_nodes, &c->blocks_per_cu));
-    if (c->blocks_per_cu < 1) return fail(c, "pt_set_scene: render kernel does not fit on a CU with this stack size");
+    if (int rc = size_stack(c)) return rc;
+    if (ptd::render_variant_node_format(c->variant) == 3) { if (int rc = ensure_wide(c)) return rc; }
     c->scene_serial++;
     return 0;
 }
@@ -196,6 +213,7 @@ PT_API int pt_set_tuning(pt_ctx* c, int blocks_per_cu, int variant)
     CK(c, hipSetDevice(c->device));
     c->tune_blocks_per_cu = blocks_per_cu;
     c->variant = variant;
+    if (ptd::render_variant_node_format(variant) == 3) { if (int rc = ensure_wide(c)) return rc; }
     CK(c, ptd::render_occupancy(c->variant, c->stack_entries, c->bvh.n_nodes, &c->blocks_per_cu));
     if (c->blocks_per_cu < 1) return fail(c, "pt_set_tuning: this kernel variant does not fit the current scene in LDS");
     return 0;
@@ -420,6 +438,7 @@ PT_API int pt_bench_traversal(pt_ctx* c, const float* rays, size_t n, int repeat
 {
     if (!c || !rays || !t_out || !prim_out || !ms_out || n == 0 || n > 0x7FFFFFFFull || repeats < 1 || node_format < 0 || node_format > 1)
         return fail(c, "pt_bench_traversal: bad argument");
+    if (node_format == 1) { if (int rc = ensure_wide(c)) return rc; }
     const uint32_t entries = node_format ? (c->bvh.wide_depth + 1u) : c->stack_entries;
     CK(c, hipSetDevice(c->device));
     float* d_rays = nullptr; float* d_t = nullptr; uint32_t* d_p = nullptr; uint32_t* d_head = nullptr;

@@ -586,11 +586,6 @@ bool build_lbvh(const float* h_verts_xyzw, size_t n_verts, const uint32_t* h_idx
         free_lbvh(out);
         return false;
     }
-    if (!build_wide4(out, stream, err)) {
-        (void)hipStreamSynchronize(stream);
-        free_lbvh(out);
-        return false;
-    }
     return true;
 }
 

@@ -37,6 +37,7 @@ struct RenderArgs {
 int render_variant_count();
 const char* render_variant_name(int variant);
 int render_variant_threads(int variant);
+int render_variant_node_format(int variant);   // 0 fp32 two-child, 1/2 16-bit two-child, 3 four-wide 8-bit
 hipError_t render_occupancy(int variant, uint32_t stack_entries, uint32_t n_nodes, int* blocks_per_cu);
 hipError_t launch_render(int variant, const RenderArgs& args, uint32_t grid_blocks, hipStream_t stream);
 hipError_t launch_items(const RenderArgs& args, hipStream_t stream);

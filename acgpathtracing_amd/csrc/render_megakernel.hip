@@ -899,6 +899,7 @@ static const VariantDesc kVariants[] = {
 };
 int render_variant_count() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
 const char* render_variant_name(int v) { return (v >= 0 && v < render_variant_count()) ? kVariants[v].name : "?"; }
+int render_variant_node_format(int v) { return (v >= 0 && v < render_variant_count()) ? kVariants[v].node_fmt : -1; }
 int render_variant_threads(int v) { return (v >= 0 && v < render_variant_count()) ? kVariants[v].threads : 0; }
 
 static size_t variant_lds(const VariantDesc& d, uint32_t stack_entries, uint32_t n_nodes)

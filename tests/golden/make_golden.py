@@ -115,6 +115,7 @@ def main():
 
     # ---- TinyObjWrapper (PathTracer_Optix/TinyObjWrapper.cpp over tinyobjloader) -------------------------------------------
     objs = ["tests/golden/obj/quads_ngons.obj", "tests/golden/obj/no_mtl.obj", "tests/golden/obj/exponent_numbers.obj",
+            "tests/golden/obj/tricky_order.obj",
             "acgpathtracing_amd/scenes/cornell_box.obj", "acgpathtracing_amd/scenes/cornell_box_diffuse.obj"]
     out["obj_names"] = np.array(objs)
     for k, rel in enumerate(objs):

@@ -51,6 +51,79 @@ def test_obj_semantics(built, tmp_path):
     assert o.dataLoaded and o.getIndexBuffer().size == 0 and o.getNumMaterials() == 0
 
 
+TRICKY_OBJ = """# chunk boundaries may fall anywhere in here
+mtllib quads_ngons.mtl
+v 0 0 0
+v 1 0 0\r
+v 1 1 0
+vt 0 0
+vn 0 0 1
+v 0 1 0
+usemtl red
+f 1 2 3
+f -4 -3 -2 -1
+f 1/1 2/1 3/1
+f 1//1 2//1 4//1
+f 1/1/1 2/1/1 3/1/1 4/1/1
+   f 2 3 4
+
+g second
+v 2 0 0
+v 2 1 0.5
+v 3 1 0
+v 3 0 -0.5
+v 2.5 -1 0
+f 5 6 7 8 9
+usemtl does_not_exist
+f -1 -2 -3
+o third
+f 5 7 10 11
+v 4 0 0
+v 4 1 0
+usemtl red
+f 9 8 7
+usemtlX
+f 1 3 4
+s off
+f 1 2"""
+
+
+def _load_with(monkeypatch, path, threads, chunk_bytes):
+    monkeypatch.setenv("ACGPT_OBJ_THREADS", str(threads))
+    monkeypatch.setenv("ACGPT_OBJ_CHUNK_BYTES", str(chunk_bytes))
+    return pt.TinyObjWrapper(path)
+
+
+@pytest.mark.parametrize("chunk_bytes,threads", [(1, 4), (5, 3), (16, 2), (37, 4), (200, 8)])
+def test_obj_chunked_ingest_equals_single_pass(built, tmp_path, monkeypatch, chunk_bytes, threads):
+    """The loader cuts the file into chunks for its parallel passes; wherever the cuts fall, vertices, indices,
+    material ids, warnings and the first error (with its line number) are those of one sequential pass."""
+    import shutil
+    shutil.copy(os.path.join(ROOT, "tests/golden/obj/quads_ngons.mtl"), tmp_path / "quads_ngons.mtl")
+    good = tmp_path / "tricky.obj"
+    good.write_bytes(TRICKY_OBJ.encode().replace(b"\\r", b"\r"))
+    crlf = tmp_path / "tricky_crlf.obj"
+    crlf.write_bytes(TRICKY_OBJ.encode().replace(b"\\r", b"").replace(b"\n", b"\r\n") + b"\r\n")
+    bad = tmp_path / "bad.obj"
+    bad.write_bytes(("\n".join(TRICKY_OBJ.replace("\\r", "").split("\n")[:24]) + "\nf 1 2 -40\nf 1 2 3\n").encode())
+    bad_vt = tmp_path / "bad_vt.obj"
+    bad_vt.write_bytes(b"v 0 0 0\nv 1 0 0\nv 0 1 0\n\n# c\nf 1/-1 2/-1 3/-1\n")      # relative vt index with no vt defined
+    for path in (good, crlf, bad, bad_vt, os.path.join(pt.SCENES, "cornell_box.obj"), os.path.join(ROOT, "tests/golden/obj/quads_ngons.obj")):
+        one = _load_with(monkeypatch, str(path), 1, 1 << 30)
+        many = _load_with(monkeypatch, str(path), threads, chunk_bytes)
+        assert one.dataLoaded == many.dataLoaded, path
+        assert one.error == many.error and one.warning == many.warning, path
+        assert np.array_equal(one.getVerticesFloat().view(np.uint32), many.getVerticesFloat().view(np.uint32)), path
+        assert np.array_equal(one.getIndexBuffer(), many.getIndexBuffer()), path
+        assert np.array_equal(one.getMaterialIndices(), many.getMaterialIndices()), path
+        assert np.array_equal(mats_bits(one), mats_bits(many)), path
+    one = _load_with(monkeypatch, str(good), 1, 1 << 30)
+    assert one.dataLoaded and one.getIndexBuffer().size // 3 == 16 and "Degenerated face" in one.warning
+    assert one.getMaterialIndices().tolist().count(0xFFFFFFFF) == 4
+    assert "Line 25" in _load_with(monkeypatch, str(bad), 1, 1 << 30).error
+    assert "Line 6" in _load_with(monkeypatch, str(bad_vt), 3, 4).error
+
+
 def test_camera_matches_reference(built):
     for c, want in zip(G["camera_in"], G["camera_uvw"]):
         cam = pt.Camera(c[0:3], c[3:6], c[6:9], float(c[9]), float(c[10]))

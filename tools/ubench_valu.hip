@@ -114,6 +114,32 @@ __global__ void __launch_bounds__(256) k_cmp_cnd4(int iters, float* out) {
     }
     if (r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 == 12345.678f) out[0] = r0;
 }
+// vcc mask, VOP3 encoding of the selects
+__global__ void __launch_bounds__(256) k_cmp_cnd4_e64(int iters, float* out) {
+    float r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7;
+    float a = 1.0001f;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            asm volatile("v_cmp_lt_f32 vcc, %0, %8\nv_cndmask_b32_e64 %0, %0, %8, vcc\nv_cndmask_b32_e64 %1, %1, %8, vcc\nv_cndmask_b32_e64 %2, %2, %8, vcc\nv_cndmask_b32_e64 %3, %3, %8, vcc\n"
+                         "v_cmp_lt_f32 vcc, %4, %8\nv_cndmask_b32_e64 %4, %4, %8, vcc\nv_cndmask_b32_e64 %5, %5, %8, vcc\nv_cndmask_b32_e64 %6, %6, %8, vcc\nv_cndmask_b32_e64 %7, %7, %8, vcc\n"
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a) : "vcc");
+    }
+    if (r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 == 12345.678f) out[0] = r0;
+}
+// vcc mask, selects with DISTINCT destination (dst != src0): is it the in-place update?
+__global__ void __launch_bounds__(256) k_cmp_cnd4_d(int iters, float* out) {
+    float r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7;
+    float a = 1.0001f, b = 2.0f;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            asm volatile("v_cmp_lt_f32 vcc, %8, %9\nv_cndmask_b32 %0, %8, %9, vcc\nv_cndmask_b32 %1, %8, %9, vcc\nv_cndmask_b32 %2, %8, %9, vcc\nv_cndmask_b32 %3, %8, %9, vcc\n"
+                         "v_cmp_lt_f32 vcc, %9, %8\nv_cndmask_b32 %4, %8, %9, vcc\nv_cndmask_b32 %5, %8, %9, vcc\nv_cndmask_b32 %6, %8, %9, vcc\nv_cndmask_b32 %7, %8, %9, vcc\n"
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b) : "vcc");
+    }
+    if (r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 == 12345.678f) out[0] = r0;
+}
 // same with the mask in an SGPR pair
 __global__ void __launch_bounds__(256) k_cmps_cnd4(int iters, float* out) {
     float r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7;
@@ -127,6 +153,34 @@ __global__ void __launch_bounds__(256) k_cmps_cnd4(int iters, float* out) {
     }
     if (r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 == 12345.678f) out[0] = r0;
 }
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define PKBODY(NAME, OP) \
+__global__ void __launch_bounds__(256) NAME(int iters, float* out) { \
+    v2f r0 = {(float)threadIdx.x, 1.f}, r1 = r0 + 1.f, r2 = r0 + 2.f, r3 = r0 + 3.f, r4 = r0 + 4.f, r5 = r0 + 5.f, r6 = r0 + 6.f, r7 = r0 + 7.f; \
+    v2f a = {1.0001f, 0.9999f}, b = {0.5f, 0.25f}; \
+    for (int i = 0; i < iters; i++) { \
+        _Pragma("unroll") for (int k = 0; k < 8; k++) { \
+            asm volatile(OP " %0, %0, %8, %9\n" OP " %1, %1, %8, %9\n" OP " %2, %2, %8, %9\n" OP " %3, %3, %8, %9\n" \
+                         OP " %4, %4, %8, %9\n" OP " %5, %5, %8, %9\n" OP " %6, %6, %8, %9\n" OP " %7, %7, %8, %9\n" \
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b)); \
+        } \
+    } \
+    v2f s = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7; if (s.x + s.y == 12345.678f) out[0] = s.x; \
+}
+#define PKBODY2(NAME, OP) \
+__global__ void __launch_bounds__(256) NAME(int iters, float* out) { \
+    v2f r0 = {(float)threadIdx.x, 1.f}, r1 = r0 + 1.f, r2 = r0 + 2.f, r3 = r0 + 3.f, r4 = r0 + 4.f, r5 = r0 + 5.f, r6 = r0 + 6.f, r7 = r0 + 7.f; \
+    v2f a = {1.0001f, 0.9999f}; \
+    for (int i = 0; i < iters; i++) { \
+        _Pragma("unroll") for (int k = 0; k < 8; k++) { \
+            asm volatile(OP " %0, %0, %8\n" OP " %1, %1, %8\n" OP " %2, %2, %8\n" OP " %3, %3, %8\n" \
+                         OP " %4, %4, %8\n" OP " %5, %5, %8\n" OP " %6, %6, %8\n" OP " %7, %7, %8\n" \
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a)); \
+        } \
+    } \
+    v2f s = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7; if (s.x + s.y == 12345.678f) out[0] = s.x; \
+}
+PKBODY(k_pkfma, "v_pk_fma_f32") PKBODY2(k_pkmul, "v_pk_mul_f32") PKBODY2(k_pkadd, "v_pk_add_f32")
 // scalar: s_and_b64 / s_bcnt1 chain next to nothing else
 __global__ void __launch_bounds__(256) k_salu(int iters, float* out) {
     unsigned long long x = 0x123456789ull + blockIdx.x; uint32_t c = 0;
@@ -151,7 +205,8 @@ int main()
                        {"v_and_b32", k_and}, {"v_add_u32", k_addu}, {"v_lshlrev_b32", k_shl}, {"v_min_u32", k_minu}, {"v_cvt_f32_ubyte1", k_cvtb},
                        {"v_cvt_f32_u32", k_cvtu}, {"v_cndmask_b32 (vcc)", k_cnd}, {"v_cmp_lt_f32 vcc", k_cmp}, {"v_cmp_lt_f32 sgpr pair", k_cmps},
                        {"v_cndmask (sgpr pair, set)", k_cnd_s}, {"v_cndmask (vcc from v_cmp)", k_cnd_init}, {"v_cmp + v_cndmask PAIR", k_cmp_cnd},
-                       {"1 v_cmp vcc + 4 v_cndmask (x0.2)", k_cmp_cnd4}, {"1 v_cmp sgpr + 4 v_cndmask (x0.2)", k_cmps_cnd4},
+                       {"1 v_cmp vcc + 4 v_cndmask (x0.2)", k_cmp_cnd4}, {"1 v_cmp sgpr + 4 v_cndmask (x0.2)", k_cmps_cnd4}, {"1 v_cmp vcc + 4 cndmask_e64 vcc", k_cmp_cnd4_e64}, {"1 v_cmp vcc + 4 cndmask dst!=src", k_cmp_cnd4_d},
+                       {"v_pk_fma_f32 (2 fma)", k_pkfma}, {"v_pk_mul_f32 (2 mul)", k_pkmul}, {"v_pk_add_f32 (2 add)", k_pkadd},
                        {"v_bfi_b32", k_bfi}, {"v_min3_f32", k_min3}, {"v_sub_f32", k_sub}, {"v_xor_b32", k_xor}, {"v_mad_u32_u24", k_mad24}, {"v_rcp_f32", k_rcp}, {"v_mov_b32", k_mov}, {"v_lshl_or_b32", k_lshlor}, {"v_and_or_b32", k_andor}, {"s_and_b64 (scalar)", k_salu}};
     const int iters = 2000;
     printf("%-26s %10s %10s %10s %10s   SIMD cycles per wave-instruction\n", "instruction", "1 w/SIMD", "2 w/SIMD", "4 w/SIMD", "8 w/SIMD");
