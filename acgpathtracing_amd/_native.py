@@ -64,7 +64,7 @@ assert C.sizeof(AreaLight) == 60
 # every symbol include/acgpt.h declares
 ABI_SYMBOLS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_set_scene", "pt_set_build_mode", "pt_scene_handle", "pt_get_bvh_info",
-    "pt_launch", "pt_resolve_framebuffer", "pt_set_partition", "pt_set_sample_chunks", "pt_set_tuning", "pt_variant_name", "pt_set_stream", "pt_get_stats",
+    "pt_launch", "pt_launch_frames", "pt_resolve_framebuffer", "pt_set_partition", "pt_set_sample_chunks", "pt_set_tuning", "pt_variant_name", "pt_set_stream", "pt_get_stats",
     "pt_trace_closest", "pt_trace_any", "pt_bench_traversal", "pt_read_morton",
     "pt_device_malloc", "pt_device_free", "pt_device_memset", "pt_copy_to_host", "pt_copy_to_device",
     "pt_host_malloc_mapped", "pt_host_free_mapped", "pt_abi_version",
@@ -100,6 +100,7 @@ def hip():
     L.pt_scene_handle.argtypes = [vp]; L.pt_scene_handle.restype = C.c_uint64
     L.pt_get_bvh_info.argtypes = [vp, C.POINTER(BvhInfo)]; L.pt_get_bvh_info.restype = C.c_int
     L.pt_launch.argtypes = [vp, C.POINTER(PathTraceParams)]; L.pt_launch.restype = C.c_int
+    L.pt_launch_frames.argtypes = [vp, C.POINTER(PathTraceParams), C.c_uint32]; L.pt_launch_frames.restype = C.c_int
     L.pt_resolve_framebuffer.argtypes = [vp, vp, vp, sz]; L.pt_resolve_framebuffer.restype = C.c_int
     L.pt_set_partition.argtypes = [vp, C.c_int, C.c_int]; L.pt_set_partition.restype = C.c_int
     L.pt_set_sample_chunks.argtypes = [vp, C.c_int]; L.pt_set_sample_chunks.restype = C.c_int

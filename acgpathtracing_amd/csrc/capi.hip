@@ -256,9 +256,12 @@ static uint32_t num_samples(int world, uint32_t w, uint32_t h)
     return rows * cols * 32u;
 }
 
-PT_API int pt_launch(pt_ctx* c, const pt_params* p)
+PT_API int pt_launch(pt_ctx* c, const pt_params* p) { return pt_launch_frames(c, p, 1u); }
+
+PT_API int pt_launch_frames(pt_ctx* c, const pt_params* p, uint32_t n_frames)
 {
     if (!c || !p) return fail(c, "pt_launch: null argument");
+    if (n_frames < 1u || n_frames > 64u) return fail(c, "pt_launch_frames: n_frames must be in [1, 64]");
     const auto t0 = std::chrono::steady_clock::now();
     if (p->width == 0 || p->height == 0) return fail(c, "pt_launch: empty image");
     if (p->width > 65535u || p->height > 65535u) return fail(c, "pt_launch: width and height are limited to 65535 (work items pack them into 16 bits each)");
@@ -295,6 +298,9 @@ PT_API int pt_launch(pt_ctx* c, const pt_params* p)
     static const uint32_t grant_by_shift[6] = {16u, 16u, 32u, 64u, 64u, 64u};
     a.grant = grant_by_shift[a.chunk_shift];
     a.chunk_spp = p->samplesPerPixel >> a.chunk_shift;
+    a.n_frames = n_frames;
+    a.sub_shift = a.chunk_shift;
+    while ((1u << (a.sub_shift - a.chunk_shift)) < n_frames) a.sub_shift++;
     {   // LCG skip-ahead: chunk k starts 2 * k * chunk_spp draws after the pixel seed (two jitter draws per sample, :730)
         uint32_t mul = 1u, add = 0u;
         for (uint32_t k = 0; k < 32u; k++) {
@@ -302,9 +308,9 @@ PT_API int pt_launch(pt_ctx* c, const pt_params* p)
             for (uint32_t i = 0; i < 2u * a.chunk_spp; i++) { add = 1664525u * add + 1013904223u; mul = 1664525u * mul; }
         }
     }
-    if (((uint64_t)num_samples(c->world, p->width, p->height) << a.chunk_shift) >= 0x7FFFFFFFull)
-        return fail(c, "pt_launch: image too large for this sample-chunk count (2^31 work items)");
-    a.total_samples = num_samples(c->world, p->width, p->height) << a.chunk_shift;
+    if (((uint64_t)num_samples(c->world, p->width, p->height) << a.sub_shift) >= 0x7FFFFFFFull)
+        return fail(c, "pt_launch: image too large for this sample-chunk count and frame batch (2^31 work items)");
+    a.total_samples = num_samples(c->world, p->width, p->height) << a.sub_shift;
     a.shard_size = ((a.total_samples + 7u) / 8u + 63u) & ~63u;
     {
         const size_t need = (size_t)a.total_samples * sizeof(uint2);
@@ -316,8 +322,8 @@ PT_API int pt_launch(pt_ctx* c, const pt_params* p)
         }
         a.items = c->d_items;
     }
-    if (a.chunk_shift) {
-        const size_t need = ((size_t)p->width * p->height << a.chunk_shift) * sizeof(float4);
+    if (a.sub_shift) {
+        const size_t need = ((size_t)p->width * p->height << a.sub_shift) * sizeof(float4);
         if (need > c->partial_bytes) {
             CK(c, hipStreamSynchronize(c->stream));
             if (c->d_partial) { (void)hipFree(c->d_partial); c->d_partial = nullptr; c->partial_bytes = 0; }
@@ -350,7 +356,7 @@ PT_API int pt_launch(pt_ctx* c, const pt_params* p)
     CK(c, hipEventRecord(c->ev0, c->stream));
     CK(c, ptd::launch_render(c->variant, a, grid, c->stream));
     CK(c, hipEventRecord(c->ev1, c->stream));
-    if (a.chunk_shift) CK(c, ptd::launch_finalize(a, c->stream));
+    if (a.sub_shift) CK(c, ptd::launch_finalize(a, c->stream));
     unsigned long long h[8];
     CK(c, hipMemcpyAsync(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     CK(c, hipStreamSynchronize(c->stream));            // CUDA_SYNC_CHECK, PathTracerMain.cpp:209
@@ -359,7 +365,7 @@ PT_API int pt_launch(pt_ctx* c, const pt_params* p)
     c->stats.radiance_rays = h[0];
     c->stats.shadow_rays = h[1];
     c->stats.paths = h[2];
-    c->stats.pixels = (uint32_t)(h[3] >> a.chunk_shift);
+    c->stats.pixels = (uint32_t)(h[3] / ((unsigned long long)n_frames << a.chunk_shift));
     c->stats.sample_chunks = 1u << a.chunk_shift;
     c->stats.trav_wave_steps = h[4];
     c->stats.trav_lane_steps = h[5];

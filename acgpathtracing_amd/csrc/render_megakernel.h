@@ -17,7 +17,7 @@ struct RenderArgs {
     pt_area_light light;
     uint32_t  useDL, useIS;
     int       rank, world;
-    uint32_t  total_samples;   // queue length: StaticWorkDistribution::numSamples(world) << chunk_shift
+    uint32_t  total_samples;   // queue length: StaticWorkDistribution::numSamples(world) << sub_shift
     uint32_t  shard_size;      // queue shard length (8 shards)
     uint32_t* queue_heads;     // 8 counters, zeroed before the launch
     unsigned long long* counters;   // [8] radiance rays, shadow rays, paths, pixels, traversal wave-steps, lane-steps, shade rounds, shade lanes
@@ -27,9 +27,15 @@ struct RenderArgs {
     // owned by its own lane (shortens the per-pixel serial chain when a GPU has few pixels).
     uint32_t  chunk_shift;     // 0 = one lane per pixel (the reference's summation order)
     uint32_t  chunk_spp;       // spp >> chunk_shift
+    // frame batches: one launch renders sub-frames frame .. frame + n_frames - 1 (each spp samples per pixel,
+    // its own tea<4>(pixel, frame) seeds) and k_finalize folds them into the accumulation buffer one after the
+    // other, exactly as n_frames separate launches would.  A work item is (pixel, sub) with
+    // sub = frame_in_batch << chunk_shift | chunk, 2^sub_shift subs per pixel (padded with empty items).
+    uint32_t  n_frames;        // >= 1
+    uint32_t  sub_shift;       // ceil_log2(n_frames) + chunk_shift
     uint32_t  lcg_mul[32];     // seed of chunk k = lcg_mul[k] * seed0 + lcg_add[k]  (2 * k * chunk_spp LCG steps)
     uint32_t  lcg_add[32];
-    float4*   partial;         // [pixel][chunk] partial sums, used when chunk_shift > 0
+    float4*   partial;         // [pixel][sub] partial sums, used when sub_shift > 0
     uint32_t  grant;           // minimum work items taken per queue atomic (1 = exactly what is needed)
     uint2*    items;           // [total_samples] work items of this launch: {px | py << 16, seed} (k_items)
 };

@@ -30,9 +30,9 @@ namespace ptd {
 extern __shared__ uint32_t lds_dyn[];
 
 // ---- pixel queue ---------------------------------------------------------------------------------
-// Work item = (pixel, sample chunk).  k_items tabulates every item of this launch once (pixel
-// coordinates from the tile order of sutil/WorkDistribution.h, seed = tea<4>(pixel, frame) skipped
-// ahead to the chunk's first sample), so taking an item inside the render kernel is one 8-byte load.
+// Work item = (pixel, sub-frame of the batch, sample chunk).  k_items tabulates every item of this launch
+// once (pixel coordinates from the tile order of sutil/WorkDistribution.h, seed = tea<4>(pixel, frame)
+// skipped ahead to the chunk's first sample), so taking an item inside the render kernel is one 8-byte load.
 // Grants: the first idle lane (ffs of the ballot) takes max(idle lanes, A.grant) consecutive items of the
 // wave's queue shard with ONE atomicAdd; the wave hands them out by popcount-prefix and keeps the rest as a
 // reserve, so most refills touch no atomic at all.  Shards are per XCD; drained shards are stolen
@@ -43,14 +43,16 @@ __global__ void k_items(const RenderArgs A)
 {
     const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
     if (item >= A.total_samples) return;
-    const uint32_t chunk = item & ((1u << A.chunk_shift) - 1u);
+    const uint32_t sub = item & ((1u << A.sub_shift) - 1u);
+    const uint32_t chunk = sub & ((1u << A.chunk_shift) - 1u);
+    const uint32_t f = sub >> A.chunk_shift;
     int x, y;
-    sample_pixel(A.world, (int)A.width, A.rank, (int)(item >> A.chunk_shift), x, y);
+    sample_pixel(A.world, (int)A.width, A.rank, (int)(item >> A.sub_shift), x, y);
     uint2 r = make_uint2(kNoItem, 0u);
-    if ((uint32_t)x < A.width && (uint32_t)y < A.height) {
+    if ((uint32_t)x < A.width && (uint32_t)y < A.height && f < A.n_frames) {
         const uint32_t pix = (uint32_t)y * A.width + (uint32_t)x;
         // :721, then skip the jitter draws of the samples before this chunk (2 per sample)
-        r = make_uint2((uint32_t)x | ((uint32_t)y << 16), A.lcg_mul[chunk] * tea4(pix, A.frame) + A.lcg_add[chunk]);
+        r = make_uint2((uint32_t)x | ((uint32_t)y << 16), A.lcg_mul[chunk] * tea4(pix, A.frame + f) + A.lcg_add[chunk]);
     }
     A.items[item] = r;
 }
@@ -60,7 +62,7 @@ struct QueueState { uint32_t shard, shards_left, res_first, res_count; };
 struct LanePixel {
     bool alive, new_path;
     uint32_t pix, px, py, seed, samples_left;
-    uint32_t chunk;      // which run of the pixel's samples this lane owns (0 when chunking is off)
+    uint32_t chunk;      // sub index: which sub-frame of the batch and which run of its samples this lane owns
     f3 result;
 };
 
@@ -95,7 +97,7 @@ __device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q,
             if (it.x != kNoItem) {
                 lp.px = it.x & 0xFFFFu; lp.py = it.x >> 16;
                 lp.pix = lp.py * A.width + lp.px;
-                lp.chunk = item & ((1u << A.chunk_shift) - 1u);
+                lp.chunk = item & ((1u << A.sub_shift) - 1u);
                 lp.seed = it.y;
                 lp.result = mk(0.0f);
                 lp.samples_left = A.chunk_spp;
@@ -108,15 +110,23 @@ __device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q,
     }
 }
 
-// mean over spp, progressive lerp, float4 + sRGB write (:782-814)
+// mean over spp, progressive lerp (:782-811)
+__device__ __forceinline__ f3 blend_frame(const f3& prev, const f3& result, uint32_t spp, uint32_t frame)
+{
+    f3 accum = result / (float)spp;
+    if (frame > 0u) {
+        const float a = 1.0f / (float)(frame + 1u);
+        accum = lerp3(prev, accum, a);
+    }
+    return accum;
+}
+
+// one sub-frame: blend, float4 + sRGB write (:782-814)
 __device__ __forceinline__ void resolve_pixel(const RenderArgs& A, uint32_t pix, const f3& result)
 {
-    f3 accum = result / (float)A.spp;
-    if (A.frame > 0u) {
-        const float a = 1.0f / (float)(A.frame + 1u);
-        const float4 prev = A.accum[pix];
-        accum = lerp3(mk(prev.x, prev.y, prev.z), accum, a);
-    }
+    f3 prev = mk(0.0f);
+    if (A.frame > 0u) { const float4 p = A.accum[pix]; prev = mk(p.x, p.y, p.z); }
+    const f3 accum = blend_frame(prev, result, A.spp, A.frame);
     A.accum[pix] = make_float4(accum.x, accum.y, accum.z, 1.0f);
     if (A.fb) A.fb[pix] = make_color(accum);
 }
@@ -125,23 +135,30 @@ __device__ __forceinline__ void resolve_pixel(const RenderArgs& A, uint32_t pix,
 // partial sum; k_finalize adds the chunks in chunk order)
 __device__ __forceinline__ void write_pixel(const RenderArgs& A, const LanePixel& lp)
 {
-    if (A.chunk_shift == 0u) resolve_pixel(A, lp.pix, lp.result);
-    else A.partial[((size_t)lp.pix << A.chunk_shift) + lp.chunk] = make_float4(lp.result.x, lp.result.y, lp.result.z, 0.0f);
+    if (A.sub_shift == 0u) resolve_pixel(A, lp.pix, lp.result);
+    else A.partial[((size_t)lp.pix << A.sub_shift) + lp.chunk] = make_float4(lp.result.x, lp.result.y, lp.result.z, 0.0f);
 }
 
-// chunked launches: sum the partial sums of every pixel of this rank in chunk order, then resolve
+// chunked / batched launches: for every pixel of this rank and every sub-frame in frame order, sum the partial
+// sums in chunk order and blend the sub-frame in — the arithmetic n_frames separate launches would do
 __global__ void k_finalize(const RenderArgs A)
 {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= (A.total_samples >> A.chunk_shift)) return;
+    if (slot >= (A.total_samples >> A.sub_shift)) return;
     int x, y;
     sample_pixel(A.world, (int)A.width, A.rank, (int)slot, x, y);
     if ((uint32_t)x >= A.width || (uint32_t)y >= A.height) return;
     const uint32_t pix = (uint32_t)y * A.width + (uint32_t)x;
-    const float4* p = A.partial + ((size_t)pix << A.chunk_shift);
-    f3 sum = mk(p[0].x, p[0].y, p[0].z);
-    for (uint32_t k = 1; k < (1u << A.chunk_shift); k++) sum += mk(p[k].x, p[k].y, p[k].z);
-    resolve_pixel(A, pix, sum);
+    f3 accum = mk(0.0f);
+    if (A.frame > 0u) { const float4 q = A.accum[pix]; accum = mk(q.x, q.y, q.z); }
+    for (uint32_t f = 0; f < A.n_frames; f++) {
+        const float4* p = A.partial + ((size_t)pix << A.sub_shift) + ((size_t)f << A.chunk_shift);
+        f3 sum = mk(p[0].x, p[0].y, p[0].z);
+        for (uint32_t k = 1; k < (1u << A.chunk_shift); k++) sum += mk(p[k].x, p[k].y, p[k].z);
+        accum = blend_frame(accum, sum, A.spp, A.frame + f);
+    }
+    A.accum[pix] = make_float4(accum.x, accum.y, accum.z, 1.0f);
+    if (A.fb) A.fb[pix] = make_color(accum);
 }
 
 __device__ __forceinline__ ShadeConsts shade_consts(const RenderArgs& A)
@@ -573,7 +590,7 @@ hipError_t launch_items(const RenderArgs& args, hipStream_t stream)
 
 hipError_t launch_finalize(const RenderArgs& args, hipStream_t stream)
 {
-    const uint32_t slots = args.total_samples >> args.chunk_shift;
+    const uint32_t slots = args.total_samples >> args.sub_shift;
     k_finalize<<<(slots + 255) / 256, 256, 0, stream>>>(args);
     return hipGetLastError();
 }

@@ -5,7 +5,7 @@
 // reference hard-codes or reads from the keyboard is a command line here, and frames go to image
 // files instead of a GLFW window:
 //
-//   acgpt_main --obj scene.obj [--width 512 --height 512] [--spp-per-launch 128] [--frames 8]
+//   acgpt_main --obj scene.obj [--width 512 --height 512] [--spp-per-launch 128] [--frames 8] [--fuse-frames 1]
 //              [--max-depth 4] [--direct-lighting] [--importance-sampling] [--device 0]
 //              [--keys "0,1,UP,UP,R"] [--out frame.png] [--dump-every k] [--zero-copy]
 //              [--orbit dx,dy] [--zoom n] [--sample-chunks c] [--build-mode 0|1]
@@ -110,11 +110,12 @@ static void updateState(OutputBuffer<uchar4>&, PathTracerState& state)    // :16
     }
 }
 
-static void LaunchCurrentFrame(OutputBuffer<uchar4>& output_buffer, PathTracerState& state)   // :184-210
+// sub_frames > 1 (--fuse-frames): that many consecutive launches of the reference's loop in one kernel launch
+static void LaunchCurrentFrame(OutputBuffer<uchar4>& output_buffer, PathTracerState& state, uint32_t sub_frames = 1)   // :184-210
 {
     uchar4* result_buffer_data = output_buffer.map();
     state.params.frameBuffer = reinterpret_cast<uint8_t*>(result_buffer_data);
-    PT_CHECK(state.context, pt_launch(state.context, &state.params));
+    PT_CHECK(state.context, pt_launch_frames(state.context, &state.params, sub_frames));
     output_buffer.unmap();
 }
 
@@ -153,7 +154,7 @@ int main(int argc, char** argv)
     std::string objfilepath, out = "frame.png", keys;
     int32_t width = 512, height = 512, frames = 8, dump_every = 0;
     bool zero_copy = false;
-    int orbit_dx = 0, orbit_dy = 0, zoom_steps = 0, sample_chunks = 0, build_mode = 1;
+    int orbit_dx = 0, orbit_dy = 0, zoom_steps = 0, sample_chunks = 0, build_mode = 1, fuse = 1;
     PathTracerState state;
     state.params.useDirectLighting = false;
     state.params.useImportanceSampling = false;
@@ -178,6 +179,7 @@ int main(int argc, char** argv)
         else if (a == "--zoom") zoom_steps = atoi(next());
         else if (a == "--sample-chunks") sample_chunks = atoi(next());
         else if (a == "--build-mode") build_mode = atoi(next());
+        else if (a == "--fuse-frames") fuse = std::min(64, std::max(1, atoi(next())));
         else { std::cerr << "unknown option " << a << std::endl; return 2; }
     }
     if (objfilepath.empty()) { std::cerr << "usage: acgpt_main --obj scene.obj [options]" << std::endl; return 2; }
@@ -220,17 +222,21 @@ int main(int argc, char** argv)
             OutputBuffer<uchar4> output_buffer(state.context, zero_copy ? OutputBufferType::ZERO_COPY : OutputBufferType::DEVICE,
                                                state.params.width, state.params.height);
             size_t next_key = 0;
-            for (int f = 0; f < frames; f++) {
+            for (int f = 0; f < frames;) {
                 auto start = std::chrono::high_resolution_clock::now();
                 if (next_key < key_list.size() && f > 0) { if (!keyCallback(state, key_list[next_key++])) break; }
                 updateState(output_buffer, state);
-                LaunchCurrentFrame(output_buffer, state);
-                ++state.params.currentFrameIdx;
+                // a batch never crosses a key press or a dump point
+                int batch = key_list.empty() ? std::min(fuse, frames - f) : 1;
+                if (dump_every > 0) batch = std::min(batch, dump_every - f % dump_every);
+                LaunchCurrentFrame(output_buffer, state, (uint32_t)batch);
+                state.params.currentFrameIdx += (uint32_t)batch;
+                f += batch - 1;
                 auto end = std::chrono::high_resolution_clock::now();
                 const double ms = std::chrono::duration<double, std::milli>(end - start).count();
                 avg_ms += ms; total_ms += ms;
-                sample_summ += samples_per_launch;
-                frame_counter++;
+                sample_summ += samples_per_launch * batch;
+                frame_counter += batch;
                 pt_stats st; pt_get_stats(state.context, &st);
                 rays += st.radiance_rays + st.shadow_rays;
                 std::cout << "\rFrame Render Time: " << (long)ms << "ms" << std::flush;
@@ -238,6 +244,7 @@ int main(int argc, char** argv)
                     std::stringstream nm; nm << out << "." << (f + 1) << ".ppm";
                     saveImage(nm.str(), reinterpret_cast<const uint8_t*>(output_buffer.getHostPointer()), width, height);
                 }
+                f++;
             }
             std::cout << std::endl;
             if (!saveImage(out, reinterpret_cast<const uint8_t*>(output_buffer.getHostPointer()), width, height))

@@ -313,11 +313,13 @@ def updateState(output_buffer, state):
         _alloc_accumulation(state)
 
 
-def LaunchCurrentFrame(output_buffer, state):
-    """PathTracerMain.cpp:184-210: map, launch, unmap, synchronised on return."""
+def LaunchCurrentFrame(output_buffer, state, sub_frames=1):
+    """PathTracerMain.cpp:184-210: map, launch, unmap, synchronised on return.  sub_frames > 1 renders that many
+    consecutive frames (currentFrameIdx, currentFrameIdx + 1, ...) in one kernel launch (pt_launch_frames); the
+    buffers end up as after sub_frames separate calls.  The caller advances currentFrameIdx."""
     L = _native.hip()
     state.params.frameBuffer = output_buffer.map() if output_buffer is not None else None
-    rc = L.pt_launch(state.context, C.byref(state.params))
+    rc = L.pt_launch_frames(state.context, C.byref(state.params), int(sub_frames))
     if output_buffer is not None:
         output_buffer.unmap()
     _check(state.context, rc, "LaunchCurrentFrame")

@@ -3,11 +3,16 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-A "step" is one launch of the hot path at the reference's launch granularity
-(LaunchCurrentFrame, PathTracerMain.cpp:184-210): 128 samples per pixel over the whole
-1920x1080 image, frame index advancing, progressive accumulation.  8 steps are one 1024-spp
-output frame = BASELINE.json configs[1] (Cornell-box OBJ, 1080p, 1024 spp, 8 bounces, importance
-sampling + direct lighting).  The scene and BVH are resident in HBM before the timed region.
+A "step" is one pass of the hot path at the reference's launch granularity (LaunchCurrentFrame,
+PathTracerMain.cpp:184-210): 128 samples per pixel over the whole 1920x1080 image, frame index
+advancing, progressive accumulation.  8 steps are one 1024-spp output frame = BASELINE.json
+configs[1] (Cornell-box OBJ, 1080p, 1024 spp, 8 bounces, importance sampling + direct lighting).
+The scene and BVH are resident in HBM before the timed region.
+
+--fuse F (default 8): F consecutive steps go into ONE kernel launch (pt_launch_frames): same seeds,
+same per-step progressive blend, buffers bit-identical to F separate pt_launch calls
+(tests/test_gpu_parity.py::test_frame_batches_equal_separate_launches); what disappears is the
+ramp-up and drain of F - 1 launches.  --fuse 1 is the reference's one-launch-per-step loop.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): every rank renders its own 8x4 pixel
 tiles (sutil/WorkDistribution.h) of the same steps, then ONE RCCL reduce of the float4
@@ -57,6 +62,7 @@ def parse():
     ap.add_argument("--cpu-spp", type=int, default=0, help="samples per pixel of the CPU baseline sample (0 = per config)")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--variant", type=int, default=-1, help="render kernel variant (-1 = library default)")
+    ap.add_argument("--fuse", type=int, default=8, help="steps per kernel launch (pt_launch_frames); 1 = one launch per step")
     ap.add_argument("--save", default="", help="write the final framebuffer as PPM (rank 0)")
     a = ap.parse_args()
     preset = {2: ("cornell_box_diffuse.obj", 8, 8), 3: ("cornell_box.obj", 32, 16), 5: ("stress_1m.obj", 2, 8)}[a.config]
@@ -160,15 +166,21 @@ def main():
         assert L.pt_set_tuning(state.context, a.blocks_per_cu, max(a.variant, 0)) == 0
     info = pt.getBvhInfo(state)
 
-    def step(frame):
-        state.params.currentFrameIdx = frame
-        rc = L.pt_launch(state.context, C.byref(state.params))
+    fuse = max(1, min(a.fuse, 64, a.steps))
+
+    def launch(first_frame, n):
+        state.params.currentFrameIdx = first_frame
+        rc = L.pt_launch_frames(state.context, C.byref(state.params), n)
         if rc != 0:
-            raise SystemExit("pt_launch failed: %s" % L.pt_last_error(state.context).decode())
+            raise SystemExit("pt_launch_frames failed: %s" % L.pt_last_error(state.context).decode())
         return pt.getStats(state)
 
-    for w in range(a.warmup):
-        step(w)
+    # warm-up: at least `warmup` steps, in launches of the same shape as the timed ones (so a kernel trace
+    # of this command averages over equal launches)
+    w = 0
+    while w < a.warmup:
+        launch(w, fuse)
+        w += fuse
     if world > 1:          # bring up the RCCL channels of the reduce outside the timed region
         if rehearse:
             host = accum.cpu(); D.reduce_accumulation(host, dst=0)
@@ -181,10 +193,13 @@ def main():
     t0 = time.perf_counter()
     rays = shadow = paths = 0
     kernel_ms = []
-    for k in range(a.steps):
-        s = step(k)
+    k = 0
+    while k < a.steps:
+        n = min(fuse, a.steps - k)
+        s = launch(k, n)
         rays += int(s.radiance_rays); shadow += int(s.shadow_rays); paths += int(s.paths)
         kernel_ms.append(float(s.kernel_ms))
+        k += n
     if world > 1:
         if rehearse:
             host = accum.cpu()
@@ -207,14 +222,15 @@ def main():
         b_ray = 64 * math.ceil(math.log2(T)) + 64
         f_ray = 48 * math.ceil(math.log2(T)) + 168
         k_avg_ms = sum(kernel_ms) / max(1, len(kernel_ms))
-        my_rays_per_launch = (rays + shadow) / max(1, a.steps)
+        n_launches = max(1, len(kernel_ms))
+        my_rays_per_launch = (rays + shadow) / n_launches
         my_pixels = a.width * a.height / world
-        algo_bytes = my_rays_per_launch * b_ray + 36.0 * my_pixels
+        algo_bytes = my_rays_per_launch * b_ray + 36.0 * my_pixels * (a.steps / n_launches)
         achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
         traffic = None
         prof = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
         default_workload = (a.config == 2 and a.scene == "cornell_box_diffuse.obj" and (a.width, a.height, a.spp, a.max_depth) == (WIDTH, HEIGHT, SPP_PER_LAUNCH, MAX_DEPTH)
-                            and world == 1 and a.variant < 0 and not a.blocks_per_cu)
+                            and world == 1 and a.variant < 0 and not a.blocks_per_cu and fuse == 8 and a.steps % 8 == 0)
         if default_workload and os.path.exists(prof):     # PMC traffic was collected on exactly this workload
             try:
                 traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
@@ -233,8 +249,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "%s (%d triangles), %dx%d, %d spp per launch x %d launches, maxDepth %d, importance sampling + direct lighting"
+            "config": {"workload": "%s (%d triangles), %dx%d, %d spp per step x %d steps, maxDepth %d, importance sampling + direct lighting"
                                    % (a.scene, info.n_tris, a.width, a.height, a.spp, a.steps, a.max_depth),
+                       "steps_per_kernel_launch": fuse, "kernel_launches": n_launches,
                        "parallelism": "pixel tiles 8x4 over %d GPU(s)%s" % (world, ", RCCL reduce of float4 accumulation" if world > 1 else ""),
                        "rays": int(all_rays), "paths": int(tot_paths), "rays_per_path": all_rays / max(1.0, tot_paths),
                        "bvh": {"nodes": info.n_nodes, "max_depth": info.max_depth, "stack_entries": info.stack_entries, "build_ms": info.build_ms}},

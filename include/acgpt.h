@@ -160,6 +160,14 @@ int      pt_get_bvh_info(pt_ctx* ctx, pt_bvh_info* out);
  * pathTracerPrograms.cu:727,780 requires spp >= 1).                           */
 int pt_launch(pt_ctx* ctx, const pt_params* params);
 
+/* A batch of sub-frames in ONE kernel launch: renders frames params->currentFrameIdx ..
+ * currentFrameIdx + n_frames - 1 (each samplesPerPixel samples per pixel with its own
+ * tea<4>(pixel, frame) seeds) and folds them into the accumulation buffer in frame order.
+ * The buffers end up bit-identical to n_frames consecutive pt_launch calls (the loop
+ * of PathTracerMain.cpp:700-730 without its per-launch synchronisation); what is saved is
+ * the ramp-up and drain of n_frames - 1 launches.  n_frames in [1, 64].              */
+int pt_launch_frames(pt_ctx* ctx, const pt_params* params, uint32_t n_frames);
+
 /* Multi-GPU pixel partition: this context renders only the pixels that
  * sutil/WorkDistribution.h:50-81 assigns to `rank` of `world` (interleaved 8x4
  * tiles, rotated per strip row); other pixels of the buffers are left

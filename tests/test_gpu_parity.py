@@ -23,8 +23,9 @@ SCENE_FULL = pt.SCENES + "/cornell_box.obj"
 SCENE_DIFFUSE = pt.SCENES + "/cornell_box_diffuse.obj"
 
 
-def _gpu_render(state, p, frames=1, out_buffer=None):
-    """Launch `frames` sub-launches through LaunchCurrentFrame; returns (accum, fb, [stats])."""
+def _gpu_render(state, p, frames=1, out_buffer=None, fuse=1, first_frame=0):
+    """Launch `frames` sub-launches through LaunchCurrentFrame, `fuse` of them per kernel launch; returns
+    (accum, fb, [stats])."""
     state.params.width, state.params.height = p.width, p.height
     keep_accum, keep_handle = state.params.accumulationBuffer, state.params.handle
     C.memmove(C.byref(state.params), C.byref(p), C.sizeof(p))
@@ -34,10 +35,13 @@ def _gpu_render(state, p, frames=1, out_buffer=None):
     if out_buffer is None:
         out_buffer = pt.OutputBuffer(pt.OutputBufferType.DEVICE, p.width, p.height, state)
     stats = []
-    for f in range(frames):
-        state.params.currentFrameIdx = f
-        pt.LaunchCurrentFrame(out_buffer, state)
+    f = 0
+    while f < frames:
+        n = min(fuse, frames - f)
+        state.params.currentFrameIdx = first_frame + f
+        pt.LaunchCurrentFrame(out_buffer, state, n)
         stats.append(pt.getStats(state))
+        f += n
     acc = pt.readAccumulation(state)
     fb = out_buffer.getHostPointer().copy()
     out_buffer.free()
@@ -196,6 +200,46 @@ def test_progressive_accumulation(full):
         ref, ref_fb, _, _ = sc.render(q, accumulation=ref, use_bvh=True)
     assert image_mse(acc, ref) < MSE_TOL
     assert np.all(acc.view(np.uint32) == ref.view(np.uint32), axis=-1).mean() > 0.50
+
+
+@pytest.mark.parametrize("chunks", [0, 1, 4])
+def test_frame_batches_equal_separate_launches(full, chunks):
+    """pt_launch_frames: n sub-frames in one kernel launch leave accumulation and framebuffer bit-identical to n
+    pt_launch calls — batches of 2, 3 (not a power of two: padded work items), 5 and 8, and a batch that
+    continues an accumulation (first frame > 0 folds into what is already there)."""
+    state, obj, sc = full
+    L = _native.hip()
+    assert L.pt_set_sample_chunks(state.context, chunks) == 0
+    try:
+        p = make_params(160, 96, 8, 5, True, True)
+        want_acc, want_fb, st1 = _gpu_render(state, p, frames=8)
+        rays1 = sum(int(s.radiance_rays + s.shadow_rays) for s in st1)
+        for fuse in (2, 3, 5, 8):
+            acc, fb, st = _gpu_render(state, p, frames=8, fuse=fuse)
+            assert np.array_equal(acc.view(np.uint32), want_acc.view(np.uint32)), "accumulation differs at fuse=%d" % fuse
+            assert np.array_equal(fb, want_fb), fuse
+            assert sum(int(s.radiance_rays + s.shadow_rays) for s in st) == rays1
+            assert all(int(s.pixels) == 160 * 96 for s in st)
+        # continuing: frames 0..2 separately, then 3..7 as one batch on top of the same buffer
+        state.params.width, state.params.height = p.width, p.height
+        out = pt.OutputBuffer(pt.OutputBufferType.DEVICE, p.width, p.height, state)
+        for f in range(3):
+            state.params.currentFrameIdx = f
+            pt.LaunchCurrentFrame(out, state)
+        state.params.currentFrameIdx = 3
+        pt.LaunchCurrentFrame(out, state, 5)
+        assert np.array_equal(pt.readAccumulation(state).view(np.uint32), want_acc.view(np.uint32))
+        assert np.array_equal(out.getHostPointer(), want_fb)
+        out.free()
+        # the running mean itself still matches the oracle
+        ref = None
+        for f in range(8):
+            q = copy_params(p); q.currentFrameIdx = f
+            ref, _, _, _ = sc.render(q, accumulation=ref, use_bvh=True)
+        assert image_mse(want_acc, ref) < MSE_TOL
+        assert L.pt_launch_frames(state.context, C.byref(state.params), 0) != 0 and L.pt_launch_frames(state.context, C.byref(state.params), 65) != 0
+    finally:
+        assert L.pt_set_sample_chunks(state.context, 1) == 0
 
 
 def test_every_kernel_variant_gives_the_same_bits(full):

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--chunks", default="1", help="comma list of sample-chunk counts to sweep")
     ap.add_argument("--partition", default="0,1", help="rank,world pixel-tile partition")
     ap.add_argument("--build-mode", type=int, default=None, help="0 Karras LBVH, 1 PLOC (library default)")
+    ap.add_argument("--fuse", type=int, default=1, help="sub-frames per kernel launch (pt_launch_frames)")
     a = ap.parse_args()
     L = _native.hip()
     path = a.scene if os.path.isabs(a.scene) else os.path.join(pt.SCENES, a.scene)
@@ -60,7 +61,7 @@ def main():
                         print("variant %d skipped: %s" % (v, L.pt_last_error(state.context).decode()))
                     continue
                 state.params.currentFrameIdx = 0
-                pt.LaunchCurrentFrame(None, state)
+                pt.LaunchCurrentFrame(None, state, a.fuse)
                 s = pt.getStats(state)
                 acc = pt.readAccumulation(state) if r == 0 else None
                 h = hashlib.sha1(acc.tobytes()).hexdigest()[:12] if acc is not None else None
