@@ -6,6 +6,7 @@
 namespace ptd {
 
 constexpr int kRenderThreads = 256;   // 4 waves per workgroup (segment-synchronous variant)
+constexpr uint32_t kMaxTimedWaves = 16384;   // stats variants stamp start / queue-empty / end per wave behind the 8 counters
 constexpr int kDefaultVariant = 1;    // persistent traversal, K40 L8, fp32 nodes, 4 waves/SIMD (no spills)
 
 struct RenderArgs {
@@ -20,7 +21,7 @@ struct RenderArgs {
     uint32_t  total_samples;   // queue length: StaticWorkDistribution::numSamples(world) << sub_shift
     uint32_t  shard_size;      // queue shard length (8 shards)
     uint32_t* queue_heads;     // 8 counters, zeroed before the launch
-    unsigned long long* counters;   // [8] radiance rays, shadow rays, paths, pixels, traversal wave-steps, lane-steps, shade rounds, shade lanes
+    unsigned long long* counters;   // [8 + 3 * kMaxTimedWaves] radiance rays, shadow rays, paths, pixels, traversal wave-steps, lane-steps, shade rounds, shade lanes
     uint32_t  stack_entries;
     uint32_t  n_lds_nodes;     // nodes staged into LDS (NODE_FMT 2), else 0
     // sample chunks: a pixel's spp samples may be split into 2^chunk_shift consecutive runs, each run

@@ -66,6 +66,7 @@ struct LanePixel {
     f3 result;
 };
 
+template <bool STATS = false>
 __device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q, uint32_t lane, unsigned long long below, LanePixel& lp)
 {
     unsigned long long idle = __ballot(!lp.alive);
@@ -77,6 +78,11 @@ __device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q,
             uint32_t base = 0;
             if (lane == leader) base = atomicAdd(&A.queue_heads[q.shard], req);
             base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+            if (STATS && lane == leader && base < A.shard_size) {       // progress of the shard: first grant past each 1/256
+                const uint32_t slot = (uint32_t)(((unsigned long long)base << 8) / A.shard_size);
+                unsigned long long* pr = A.counters + 8 + 3 * kMaxTimedWaves + 256u * q.shard + slot;
+                if (*pr == 0ull) *pr = __builtin_amdgcn_s_memrealtime();
+            }
             const uint32_t shard_begin = q.shard * A.shard_size;
             uint32_t shard_end = shard_begin + A.shard_size;
             if (shard_end > A.total_samples) shard_end = A.total_samples;
@@ -311,6 +317,9 @@ k_render_pw(const RenderArgs A)
     QueueState q; q.shard = xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0;
     unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0;
     unsigned long long n_steps = 0, n_lane_steps = 0, n_rounds = 0, n_lane_rounds = 0;
+    // STATS only: 100 MHz stamps of this wave's start, of the moment it found the queue empty, and of its end
+    unsigned long long t_start = 0, t_drain = 0;
+    if (STATS) t_start = __builtin_amdgcn_s_memrealtime();
 
     LanePixel lp; lp.alive = false; lp.new_path = false; lp.pix = lp.px = lp.py = lp.seed = lp.samples_left = lp.chunk = 0; lp.result = mk(0.0f);
     uint32_t pseed = 0;
@@ -378,7 +387,8 @@ k_render_pw(const RenderArgs A)
         n_paths += (unsigned long long)__popcll(__ballot(end));
         n_pixels += (unsigned long long)__popcll(__ballot(finished));
 
-        refill_lanes(A, q, lane, below, lp);
+        refill_lanes<STATS>(A, q, lane, below, lp);
+        if (STATS && t_drain == 0ull && q.shards_left == 0u && q.res_count == 0u) t_drain = __builtin_amdgcn_s_memrealtime();
         if (__ballot(lp.alive) == 0ull) { if (q.shards_left == 0u && q.res_count == 0u) break; else continue; }
 
         bool start_radiance = segment_done && !end;
@@ -573,6 +583,14 @@ k_render_pw(const RenderArgs A)
         atomicAdd(&A.counters[5], n_lane_steps);
         atomicAdd(&A.counters[6], n_rounds);
         atomicAdd(&A.counters[7], n_lane_rounds);
+        if (STATS) {
+            const uint32_t w = blockIdx.x * (THREADS / 64) + wave;
+            if (w < kMaxTimedWaves) {
+                A.counters[8 + 3 * w] = t_start;
+                A.counters[8 + 3 * w + 1] = t_drain;
+                A.counters[8 + 3 * w + 2] = __builtin_amdgcn_s_memrealtime();
+            }
+        }
     }
 }
 

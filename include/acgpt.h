@@ -220,6 +220,12 @@ int pt_trace_any(pt_ctx* ctx, const float* rays, size_t n, uint8_t* hit_out);
  * with a triangle round.  Not used by the render path.                                                   */
 int pt_bench_traversal(pt_ctx* ctx, const float* rays, size_t n, int repeats, int node_format, float* t_out, uint32_t* prim_out, float* ms_out,
                        uint64_t* counters_out);
+/* Diagnostic: after a launch of a "+ scheduler stats" kernel variant, three 100 MHz stamps per wave (start,
+ * first time it found the work queue empty, end; 0 = wave did not run), HOST output of 3 * max_waves values. */
+int pt_debug_wave_times(pt_ctx* ctx, uint64_t* out, size_t max_waves);
+/* ... and, per work-queue shard (8), the stamp of the first grant past each 1/256 of the shard: HOST output of
+ * 8 * 256 values (0 = never reached by a stamped grant). */
+int pt_debug_queue_progress(pt_ctx* ctx, uint64_t* out);
 /* Sorted (morton, triangle) pairs of the last build, HOST outputs of n_tris. */
 int pt_read_morton(pt_ctx* ctx, uint32_t* codes_sorted, uint32_t* prims_sorted);
 
