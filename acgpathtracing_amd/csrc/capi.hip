@@ -442,10 +442,10 @@ PT_API int pt_trace_any(pt_ctx* c, const float* rays, size_t n, uint8_t* hit_out
 PT_API int pt_bench_traversal(pt_ctx* c, const float* rays, size_t n, int repeats, int node_format, float* t_out, uint32_t* prim_out, float* ms_out,
                               uint64_t* counters_out)
 {
-    if (!c || !rays || !t_out || !prim_out || !ms_out || n == 0 || n > 0x7FFFFFFFull || repeats < 1 || node_format < 0 || node_format > 1)
+    if (!c || !rays || !t_out || !prim_out || !ms_out || n == 0 || n > 0x7FFFFFFFull || repeats < 1 || node_format < 0 || node_format > 2)
         return fail(c, "pt_bench_traversal: bad argument");
     if (node_format == 1) { if (int rc = ensure_wide(c)) return rc; }
-    const uint32_t entries = node_format ? (c->bvh.wide_depth + 1u) : c->stack_entries;
+    const uint32_t entries = node_format == 1 ? (c->bvh.wide_depth + 1u) : c->stack_entries;
     CK(c, hipSetDevice(c->device));
     float* d_rays = nullptr; float* d_t = nullptr; uint32_t* d_p = nullptr; uint32_t* d_head = nullptr;
     int bpc = 0;

@@ -656,7 +656,7 @@ k_trace_any(const DeviceScene sc, uint32_t stack_entries, const float* __restric
 // grant).  No path state, no shading: few registers, full occupancy, lanes (almost) never idle.  It
 // answers one question — how fast could traversal alone go on this scene and ray mix — and is
 // bit-checked against pt_trace_closest / pt_trace_any.
-template <int FETCH_K, int LEAF_K>
+template <int FETCH_K, int LEAF_K, bool FMA_SLAB = false>
 __global__ void __launch_bounds__(256)
 k_trace_stream(const DeviceScene sc, uint32_t stack_entries, const float4* __restrict__ rays, uint32_t n,
                uint32_t* __restrict__ head, float* __restrict__ t_out, uint32_t* __restrict__ prim_out,
@@ -670,7 +670,7 @@ k_trace_stream(const DeviceScene sc, uint32_t stack_entries, const float4* __res
     bool drained = false;
     // ray in flight
     uint32_t rid = 0xFFFFFFFFu;
-    f3 ro = mk(0.0f), rd = mk(0.0f, 0.0f, 1.0f), rinv = mk(1.0f);
+    f3 ro = mk(0.0f), rd = mk(0.0f, 0.0f, 1.0f), rinv = mk(1.0f), roi = mk(0.0f);
     float rtmin = 0.0f, rtmax = 0.0f, best_t = 0.0f;
     int best_slot = -1; uint32_t best_prim = 0xFFFFFFFFu;
     int node = kSentinel, sp = 0, tos = kSentinel;
@@ -707,6 +707,7 @@ k_trace_stream(const DeviceScene sc, uint32_t stack_entries, const float4* __res
                     ro = mk(a.x, a.y, a.z); rd = mk(a.w, b.x, b.y); rtmin = b.z;
                     any_ray = b.w < 0.0f; rtmax = fabsf(b.w);
                     rinv = mk(fast_rcp(rd.x), fast_rcp(rd.y), fast_rcp(rd.z));
+                    if (FMA_SLAB) roi = mk(-(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z));
                     best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu; any_hit = false;
                     node = sc.n_tris ? 0 : kSentinel; sp = 0;
                 }
@@ -724,14 +725,24 @@ k_trace_stream(const DeviceScene sc, uint32_t stack_entries, const float4* __res
             const BvhNode* np = sc.nodes + node;
             const float4 a = np->a, b = np->b, c = np->c;
             const int4 ch = np->d;
-            float x0 = (a.x - ro.x) * rinv.x, x1 = (a.w - ro.x) * rinv.x;
-            float y0 = (a.y - ro.y) * rinv.y, y1 = (b.x - ro.y) * rinv.y;
-            float z0 = (a.z - ro.z) * rinv.z, z1 = (b.y - ro.z) * rinv.z;
+            float x0, x1, y0, y1, z0, z1, u0, u1, v0, v1, w0, w1;
+            if (FMA_SLAB) {        // experiment: t = p * (1/d) - o/d, one full-rate fma per plane (looser rounding: timing only)
+                x0 = __builtin_fmaf(a.x, rinv.x, roi.x); x1 = __builtin_fmaf(a.w, rinv.x, roi.x);
+                y0 = __builtin_fmaf(a.y, rinv.y, roi.y); y1 = __builtin_fmaf(b.x, rinv.y, roi.y);
+                z0 = __builtin_fmaf(a.z, rinv.z, roi.z); z1 = __builtin_fmaf(b.y, rinv.z, roi.z);
+                u0 = __builtin_fmaf(b.z, rinv.x, roi.x); u1 = __builtin_fmaf(c.y, rinv.x, roi.x);
+                v0 = __builtin_fmaf(b.w, rinv.y, roi.y); v1 = __builtin_fmaf(c.z, rinv.y, roi.y);
+                w0 = __builtin_fmaf(c.x, rinv.z, roi.z); w1 = __builtin_fmaf(c.w, rinv.z, roi.z);
+            } else {
+                x0 = (a.x - ro.x) * rinv.x; x1 = (a.w - ro.x) * rinv.x;
+                y0 = (a.y - ro.y) * rinv.y; y1 = (b.x - ro.y) * rinv.y;
+                z0 = (a.z - ro.z) * rinv.z; z1 = (b.y - ro.z) * rinv.z;
+                u0 = (b.z - ro.x) * rinv.x; u1 = (c.y - ro.x) * rinv.x;
+                v0 = (b.w - ro.y) * rinv.y; v1 = (c.z - ro.y) * rinv.y;
+                w0 = (c.x - ro.z) * rinv.z; w1 = (c.w - ro.z) * rinv.z;
+            }
             float n0 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), rtmin));
             float f0 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1)) * kFarWiden;
-            float u0 = (b.z - ro.x) * rinv.x, u1 = (c.y - ro.x) * rinv.x;
-            float v0 = (b.w - ro.y) * rinv.y, v1 = (c.z - ro.y) * rinv.y;
-            float w0 = (c.x - ro.z) * rinv.z, w1 = (c.w - ro.z) * rinv.z;
             float n1 = fmaxf(fmaxf(fminf(u0, u1), fminf(v0, v1)), fmaxf(fminf(w0, w1), rtmin));
             float f1 = fminf(fminf(fmaxf(u0, u1), fmaxf(v0, v1)), fmaxf(w0, w1)) * kFarWiden;
             f0 = fminf(f0, best_t * kTieWiden);
@@ -889,19 +900,20 @@ k_trace_stream_w4(const DeviceScene sc, uint32_t stack_entries, const float4* __
 hipError_t launch_trace_stream(int fmt, const DeviceScene& sc, uint32_t stack_entries, const float* d_rays, uint32_t n, uint32_t* d_head,
                                float* d_t, uint32_t* d_prim, unsigned long long* d_counters, uint32_t grid_blocks, hipStream_t stream)
 {
-    const size_t lds = (size_t)(fmt ? 8 : 4) * stack_entries * 256u;
-    const void* k = fmt ? (const void*)k_trace_stream_w4<8, 8> : (const void*)k_trace_stream<8, 8>;
+    const size_t lds = (size_t)(fmt == 1 ? 8 : 4) * stack_entries * 256u;
+    const void* k = fmt == 1 ? (const void*)k_trace_stream_w4<8, 8> : (fmt == 2 ? (const void*)k_trace_stream<8, 8, true> : (const void*)k_trace_stream<8, 8>);
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    if (fmt) k_trace_stream_w4<8, 8><<<grid_blocks, 256, lds, stream>>>(sc, stack_entries, (const float4*)d_rays, n, d_head, d_t, d_prim, d_counters);
+    if (fmt == 1) k_trace_stream_w4<8, 8><<<grid_blocks, 256, lds, stream>>>(sc, stack_entries, (const float4*)d_rays, n, d_head, d_t, d_prim, d_counters);
+    else if (fmt == 2) k_trace_stream<8, 8, true><<<grid_blocks, 256, lds, stream>>>(sc, stack_entries, (const float4*)d_rays, n, d_head, d_t, d_prim, d_counters);
     else k_trace_stream<8, 8><<<grid_blocks, 256, lds, stream>>>(sc, stack_entries, (const float4*)d_rays, n, d_head, d_t, d_prim, d_counters);
     return hipGetLastError();
 }
 
 hipError_t trace_stream_occupancy(int fmt, uint32_t stack_entries, int* blocks_per_cu)
 {
-    const size_t lds = (size_t)(fmt ? 8 : 4) * stack_entries * 256u;
-    const void* k = fmt ? (const void*)k_trace_stream_w4<8, 8> : (const void*)k_trace_stream<8, 8>;
+    const size_t lds = (size_t)(fmt == 1 ? 8 : 4) * stack_entries * 256u;
+    const void* k = fmt == 1 ? (const void*)k_trace_stream_w4<8, 8> : (fmt == 2 ? (const void*)k_trace_stream<8, 8, true> : (const void*)k_trace_stream<8, 8>);
     hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k, 256, lds);

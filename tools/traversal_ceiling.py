@@ -88,12 +88,13 @@ def main():
     anyr = np.ascontiguousarray(R[~closest]); anyr[:, 7] = -anyr[:, 7]
     h = np.zeros(anyr.shape[0], np.uint8)
     assert L.pt_trace_any(state.context, anyr.ctypes.data, anyr.shape[0], h.ctypes.data) == 0
+    assert L.pt_bench_traversal(state.context, R.ctypes.data, 64, 1, 1, np.zeros(64, np.float32).ctypes.data, np.zeros(64, np.uint32).ctypes.data, C.byref(C.c_float()), None) == 0   # builds the four-wide tree
     info = pt.getBvhInfo(state)
     print("scene %s (%d triangles): %d rays (%d camera, %d shadow, %d bounce); closest-hit rate %.2f, occluded %.2f"
           % (a.scene, info.n_tris, n, n0, int((~closest).sum()), n - n0 - int((~closest).sum()), float((pc != 0xFFFFFFFF).mean()), float(h.mean())))
     print("two-child tree: %d nodes, depth %d, build %.2f ms; four-wide tree: %d nodes, depth %d, collapse %.2f ms (host)"
           % (info.n_nodes, info.max_depth, info.build_ms, info.wide_nodes, info.wide_depth, info.wide_ms))
-    for fmt, name in ((0, "two-child fp32 nodes (64 B)"), (1, "four-wide 8-bit nodes (48 B)")):
+    for fmt, name in ((0, "two-child fp32 nodes (64 B)"), (1, "four-wide 8-bit nodes (48 B)"), (2, "two-child, fma slab test")):
         t_out = np.zeros(n, np.float32); p_out = np.zeros(n, np.uint32); ms = C.c_float()
         cnt = np.zeros(5, np.uint64)
         assert L.pt_bench_traversal(state.context, R.ctypes.data, n, a.repeats, fmt, t_out.ctypes.data, p_out.ctypes.data, C.byref(ms), cnt.ctypes.data) == 0, L.pt_last_error(state.context)
