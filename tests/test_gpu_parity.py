@@ -452,6 +452,18 @@ def test_headless_app_matches_the_python_path(full, tmp_path):
     finally:
         assert L.pt_set_sample_chunks(state.context, 1) == 0
     assert np.array_equal(got, fb[::-1, :, :3])
+    # --fuse-frames: 5 frames as batches of 4 + 1 (with a dump after frame 2 that splits the first batch): same bytes
+    # as one launch per frame
+    outs = {}
+    for fuse in (1, 4):
+        o = str(tmp_path / ("fuse%d.ppm" % fuse))
+        r = subprocess.run([exe, "--obj", SCENE_FULL, "--width", "96", "--height", "64", "--spp-per-launch", "8", "--frames", "5", "--max-depth", "5",
+                            "--direct-lighting", "--importance-sampling", "--fuse-frames", str(fuse), "--dump-every", "2", "--out", o],
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        assert "Total Samples 40" in r.stdout
+        outs[fuse] = (open(o, "rb").read(), open(o + ".2.ppm", "rb").read(), open(o + ".4.ppm", "rb").read())
+    assert outs[1] == outs[4]
 
 
 def test_full_size_properties(diffuse):
