@@ -34,6 +34,7 @@ struct pt_ctx {
     int tune_blocks_per_cu = 0;   // user override
     int build_mode = 1;           // 0 Karras LBVH, 1 PLOC over the Morton order
     int variant = ptd::kDefaultVariant;   // render kernel variant (render_megakernel.hip)
+    bool variant_auto = true;             // until pt_set_tuning picks one: chosen per scene size in pt_set_scene
     uint32_t* d_queue = nullptr;              // 8 shard heads
     unsigned long long* d_counters = nullptr; // 8 counters
     int rank = 0, world = 1;
@@ -162,6 +163,7 @@ PT_API int pt_set_scene(pt_ctx* c, const float* verts_xyzw, size_t n_verts, cons
         CK(c, hipMemcpy(c->d_mats, mats, n_mats * sizeof(pt_material), hipMemcpyHostToDevice));
     }
     c->n_mats = (uint32_t)n_mats;
+    if (c->variant_auto) c->variant = c->bvh.n_tris > ptd::kLargeSceneTris ? ptd::kLargeSceneVariant : ptd::kDefaultVariant;
     if (int rc = size_stack(c)) return rc;
     if (ptd::render_variant_node_format(c->variant) == 3) { if (int rc = ensure_wide(c)) return rc; }
     c->scene_serial++;
@@ -213,6 +215,7 @@ PT_API int pt_set_tuning(pt_ctx* c, int blocks_per_cu, int variant)
     CK(c, hipSetDevice(c->device));
     c->tune_blocks_per_cu = blocks_per_cu;
     c->variant = variant;
+    c->variant_auto = false;
     if (ptd::render_variant_node_format(variant) == 3) { if (int rc = ensure_wide(c)) return rc; }
     CK(c, ptd::render_occupancy(c->variant, c->stack_entries, c->bvh.n_nodes, &c->blocks_per_cu));
     if (c->blocks_per_cu < 1) return fail(c, "pt_set_tuning: this kernel variant does not fit the current scene in LDS");

@@ -928,8 +928,8 @@ struct VariantDesc { RenderKernel k; int threads; int node_fmt; const char* name
 // <SHADE_K, LEAF_K, NODE_FMT, THREADS>.
 static const VariantDesc kVariants[] = {
     {k_render, 256, 0, "sync fp32-nodes"},
-    {k_render_pw<48, 8, 0, 256, 4, false, 0, 1>, 256, 0, "pw K48 L8 fp32 w4, register stack top (default)"},
-    {k_render_pw<48, 8, 0, 256, 4, true, 0, 1>, 256, 0, "default + scheduler stats"},
+    {k_render_pw<48, 12, 0, 256, 4, false, 0, 1>, 256, 0, "pw K48 L12 fp32 w4, register stack top (default)"},
+    {k_render_pw<48, 12, 0, 256, 4, true, 0, 1>, 256, 0, "default + scheduler stats"},
     {k_render_pw<40, 8, 0, 256, 4, false, 0, 1>, 256, 0, "pw K40 L8 fp32 w4, register stack top"},
     {k_render_pw<48, 8, 0, 256, 4, false>, 256, 0, "pw K48 L8 fp32 w4, LDS-only stack"},
     {k_render_pw<48, 8, 0, 256, 5, false, 0, 1>, 256, 0, "pw K48 L8 fp32 w5 (register-capped, spills)"},
@@ -943,6 +943,9 @@ static const VariantDesc kVariants[] = {
     {k_render_pw<48, 16, 3, 256, 4, false, 0, 1>, 256, 3, "pw K48 L16 four-wide"},
     {k_render_pw<40, 8, 3, 256, 4, false, 0, 1>, 256, 3, "pw K40 L8 four-wide"},
     {k_render_pw<48, 8, 3, 256, 5, false, 0, 1>, 256, 3, "pw K48 L8 four-wide w5"},
+    {k_render_pw<48, 8, 0, 256, 4, false, 0, 1>, 256, 0, "pw K48 L8 fp32 w4 (kLargeSceneVariant: chosen automatically above 100 k triangles)"},
+    {k_render_pw<48, 16, 0, 256, 4, false, 0, 1>, 256, 0, "pw K48 L16 fp32 w4"},
+    {k_render_pw<44, 12, 0, 256, 4, false, 0, 1>, 256, 0, "pw K44 L12 fp32 w4"},
 };
 int render_variant_count() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
 const char* render_variant_name(int v) { return (v >= 0 && v < render_variant_count()) ? kVariants[v].name : "?"; }
