@@ -471,7 +471,8 @@ def test_full_size_properties(diffuse):
     at this size, so: (a) the segment-synchronous kernel and the default kernel agree bit for bit,
     counters included; (b) the 8-way tile partition sums to the whole image bit for bit; (c) counter
     identities hold (paths = W*H*spp, pixels = W*H); (d) two consecutive frames follow the running-mean
-    rule exactly: acc_1 == lerp(acc_0, frame_1_alone, 1/2)."""
+    rule exactly: acc_1 == lerp(acc_0, frame_1_alone, 1/2); (e) a batch of 8 steps in one kernel launch (what
+    bench.py times) leaves the same bits as 8 launches."""
     state, obj, _ = diffuse
     L = _native.hip()
     W, H, S = 1920, 1080, 128
@@ -520,6 +521,15 @@ def test_full_size_properties(diffuse):
         f1 = half_f1 * np.float32(2.0)
         expect = whole[..., :3] + np.float32(0.5) * (f1 - whole[..., :3])
         assert np.array_equal(expect.astype(np.float32).view(np.uint32), two[..., :3].view(np.uint32))
+        # (e) the bench's default shape: 8 steps in one kernel launch == 8 launches, whole image and one rank's tiles
+        assert L.pt_set_sample_chunks(state.context, 0) == 0
+        for part in ((0, 1), (3, 8)):
+            assert L.pt_set_partition(state.context, *part) == 0
+            sep, sep_fb, st_sep = _gpu_render(state, q, frames=8)
+            one, one_fb, st_one = _gpu_render(state, q, frames=8, fuse=8)
+            assert len(st_one) == 1 and st_one[0].paths == sum(t.paths for t in st_sep)
+            assert st_one[0].radiance_rays + st_one[0].shadow_rays == sum(t.radiance_rays + t.shadow_rays for t in st_sep)
+            assert np.array_equal(sep.view(np.uint32), one.view(np.uint32)) and np.array_equal(sep_fb, one_fb), part
     finally:
         L.pt_set_partition(state.context, 0, 1)
         L.pt_set_tuning(state.context, 0, _DEFAULT_VARIANT)
