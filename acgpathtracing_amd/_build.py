@@ -14,8 +14,8 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 HOST = os.path.join(PKG, "host")
 
-HIP_SOURCES = ["capi.hip", "lbvh_build.hip", "wide_bvh.hip", "render_megakernel.hip"]
-HIP_HEADERS = ["pt_device.h", "lbvh_build.h", "render_megakernel.h"]
+HIP_SOURCES = ["capi.hip", "lbvh_build.hip", "wide_bvh.hip", "render_megakernel.hip", "selftest.hip"]
+HIP_HEADERS = ["pt_device.h", "pt_shading.h", "lbvh_build.h", "render_megakernel.h", "selftest.h"]
 HOST_SOURCES = ["host_capi.cpp", "TinyObjWrapper.cpp", "Camera.cpp", "Trackball.cpp", "ImageIO.cpp"]
 
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden", "-std=c++17"]

@@ -65,7 +65,7 @@ assert C.sizeof(AreaLight) == 60
 ABI_SYMBOLS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_set_scene", "pt_set_build_mode", "pt_scene_handle", "pt_get_bvh_info",
     "pt_launch", "pt_launch_frames", "pt_resolve_framebuffer", "pt_set_partition", "pt_set_sample_chunks", "pt_set_tuning", "pt_variant_name", "pt_set_stream", "pt_get_stats",
-    "pt_trace_closest", "pt_trace_any", "pt_bench_traversal", "pt_debug_wave_times", "pt_debug_queue_progress", "pt_read_morton",
+    "pt_trace_closest", "pt_trace_any", "pt_bench_traversal", "pt_selftest", "pt_debug_wave_times", "pt_debug_queue_progress", "pt_read_morton",
     "pt_device_malloc", "pt_device_free", "pt_device_memset", "pt_copy_to_host", "pt_copy_to_device",
     "pt_host_malloc_mapped", "pt_host_free_mapped", "pt_abi_version",
 ]
@@ -111,6 +111,7 @@ def hip():
     L.pt_trace_closest.argtypes = [vp, vp, sz, vp, vp]; L.pt_trace_closest.restype = C.c_int
     L.pt_trace_any.argtypes = [vp, vp, sz, vp]; L.pt_trace_any.restype = C.c_int
     L.pt_bench_traversal.argtypes = [vp, vp, sz, C.c_int, C.c_int, vp, vp, C.POINTER(C.c_float), vp]; L.pt_bench_traversal.restype = C.c_int
+    L.pt_selftest.argtypes = [vp, C.c_int, vp, sz, vp]; L.pt_selftest.restype = C.c_int
     L.pt_debug_wave_times.argtypes = [vp, vp, sz]; L.pt_debug_wave_times.restype = C.c_int
     L.pt_debug_queue_progress.argtypes = [vp, vp]; L.pt_debug_queue_progress.restype = C.c_int
     L.pt_read_morton.argtypes = [vp, vp, vp]; L.pt_read_morton.restype = C.c_int

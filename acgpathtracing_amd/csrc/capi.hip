@@ -13,6 +13,7 @@
 #include "lbvh_build.h"
 #include "pt_device.h"
 #include "render_megakernel.h"
+#include "selftest.h"
 
 #define PT_API extern "C" __attribute__((visibility("default")))
 
@@ -481,6 +482,32 @@ PT_API int pt_bench_traversal(pt_ctx* c, const float* rays, size_t n, int repeat
     if (d_head) (void)hipFree(d_head);
     if (e != hipSuccess) return fail(c, std::string("pt_bench_traversal: ") + hipGetErrorString(e));
     *ms_out = best;
+    return 0;
+}
+
+// in / out sizes per element, in dwords (op 1: in = {seed, count}, out = 2 * count)
+PT_API int pt_selftest(pt_ctx* c, int op, const void* in, size_t n, void* out)
+{
+    static const int in_dw[11] = {2, 2, 3, 10, 10, 10, 10, 10, 10, 7, 4}, out_dw[11] = {1, 0, 1, 3, 3, 3, 3, 3, 3, 4, 2};
+    if (!c || !in || !out || op < 0 || op > 10 || n == 0 || n > (1u << 24)) return fail(c, "pt_selftest: bad argument");
+    CK(c, hipSetDevice(c->device));
+    size_t in_bytes = n * (size_t)in_dw[op] * 4, out_bytes = n * (size_t)out_dw[op] * 4;
+    uint32_t launch_n = (uint32_t)n;
+    if (op == 1) {
+        const uint32_t count = ((const uint32_t*)in)[1];
+        if (n != 1 || count == 0 || count > (1u << 22)) return fail(c, "pt_selftest: op 1 takes one {seed, count} record");
+        in_bytes = 8; out_bytes = (size_t)count * 8; launch_n = 1;
+    }
+    uint32_t* d_in = nullptr; uint32_t* d_out = nullptr;
+    hipError_t e = hipMalloc((void**)&d_in, in_bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_out, out_bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = ptd::launch_selftest(op, d_in, launch_n, d_out, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(c, std::string("pt_selftest: ") + hipGetErrorString(e));
     return 0;
 }
 

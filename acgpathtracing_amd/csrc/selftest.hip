@@ -1,0 +1,66 @@
+// selftest.hip — evaluates the device-side building blocks of the render kernel (the very functions
+// pt_device.h / pt_shading.h inline into it) on caller-supplied inputs, so that tests can hold the GPU
+// implementations against the golden vectors generated from the reference's own host-compilable sources
+// (tests/golden/reference_vectors.npz: cuda/random.h, cuda/helpers.h, sutil/vec_math.h,
+// sutil/WorkDistribution.h).  Not on the render path.
+#include "pt_device.h"
+#include "pt_shading.h"
+#include "selftest.h"
+
+namespace ptd {
+
+// op: see pt_selftest in include/acgpt.h
+__global__ void k_selftest(int op, const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (op == 1) {                                   // one LCG stream: in = {seed, count}; out = states[count], values[count]
+        if (i != 0) return;
+        uint32_t seed = in[0];
+        const uint32_t count = in[1];
+        for (uint32_t k = 0; k < count; k++) { const float v = rnd(seed); out[k] = seed; out[count + k] = __float_as_uint(v); }
+        return;
+    }
+    if (i >= n) return;
+    const float* fin = (const float*)in;
+    float* fout = (float*)out;
+    if (op == 0) { out[i] = tea4(in[2 * i], in[2 * i + 1]); return; }
+    if (op == 2) { out[i] = make_color(mk(fin[3 * i], fin[3 * i + 1], fin[3 * i + 2])); return; }
+    if (op >= 3 && op <= 8) {                        // in: a xyz, b xyz, c xyz, s
+        const float* r = fin + 10 * i;
+        const f3 a = mk(r[0], r[1], r[2]), b = mk(r[3], r[4], r[5]), c = mk(r[6], r[7], r[8]);
+        const float s = r[9];
+        f3 o;
+        switch (op) {
+            case 3: o = normalize(a); break;
+            case 4: o = reflect(a, b); break;
+            case 5: o = faceforward(a, b, c); break;
+            case 6: o = lerp3(a, b, s); break;
+            case 7: o = cross(a, b); break;
+            default: o = a / s; break;
+        }
+        fout[3 * i] = o.x; fout[3 * i + 1] = o.y; fout[3 * i + 2] = o.z;
+        return;
+    }
+    if (op == 9) {                                   // in: i xyz, n xyz, ior; out: r xyz, ok
+        const float* r = fin + 7 * i;
+        f3 o = mk(0.0f);
+        const bool ok = refract_dir(o, mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5]), r[6]);
+        fout[4 * i] = o.x; fout[4 * i + 1] = o.y; fout[4 * i + 2] = o.z; out[4 * i + 3] = ok ? 1u : 0u;
+        return;
+    }
+    if (op == 10) {                                  // in: world, width, rank, sample; out: x, y
+        const int* r = (const int*)in + 4 * i;
+        int x, y;
+        sample_pixel(r[0], r[1], r[2], r[3], x, y);
+        ((int*)out)[2 * i] = x; ((int*)out)[2 * i + 1] = y;
+        return;
+    }
+}
+
+hipError_t launch_selftest(int op, const uint32_t* d_in, uint32_t n, uint32_t* d_out, hipStream_t stream)
+{
+    k_selftest<<<(n + 255) / 256, 256, 0, stream>>>(op, d_in, n, d_out);
+    return hipGetLastError();
+}
+
+}  // namespace ptd

@@ -221,6 +221,15 @@ int pt_trace_any(pt_ctx* ctx, const float* rays, size_t n, uint8_t* hit_out);
  * with a triangle round.  Not used by the render path.                                                   */
 int pt_bench_traversal(pt_ctx* ctx, const float* rays, size_t n, int repeats, int node_format, float* t_out, uint32_t* prim_out, float* ms_out,
                        uint64_t* counters_out);
+/* Test hook: evaluates the device functions the render kernel is built from on HOST inputs (n elements), so that
+ * the GPU implementations can be held against golden vectors of the reference's own code directly.
+ *   op 0  tea<4> (cuda/random.h:31-46)            in uint32[n][2]                 out uint32[n]
+ *   op 1  lcg / rnd stream (cuda/random.h:49-67)  in {seed, count}, n = 1         out uint32 states[count], float values[count]
+ *   op 2  make_color (cuda/helpers.h:35-62)       in float[n][3]                  out uchar4[n]
+ *   op 3..8 normalize, reflect, faceforward, lerp, cross, a / s (sutil/vec_math.h)  in float[n][10] = a, b, c, s   out float[n][3]
+ *   op 9  refract (cuda/helpers.h:107-137)        in float[n][7] = i, n, ior      out float[n][4] = r, ok (uint32)
+ *   op 10 StaticWorkDistribution::getSamplePixel (sutil/WorkDistribution.h:59-81)  in int32[n][4] = world, width, rank, sample   out int32[n][2] */
+int pt_selftest(pt_ctx* ctx, int op, const void* in, size_t n, void* out);
 /* Diagnostic: after a launch of a "+ scheduler stats" kernel variant, three 100 MHz stamps per wave (start,
  * first time it found the work queue empty, end; 0 = wave did not run), HOST output of 3 * max_waves values. */
 int pt_debug_wave_times(pt_ctx* ctx, uint64_t* out, size_t max_waves);

@@ -1,0 +1,89 @@
+"""The GPU's own building blocks against the REFERENCE's golden vectors, directly (no oracle in between).
+
+pt_selftest runs the device functions that pt_device.h / pt_shading.h inline into the render kernel on the
+inputs of tests/golden/reference_vectors.npz, which tests/golden/make_golden.py generated from the reference's
+host-compilable sources (cuda/random.h, cuda/helpers.h, sutil/vec_math.h, sutil/WorkDistribution.h).
+Integer work and fp32 arithmetic made of IEEE-exact operations are compared bit for bit; make_color goes through
+powf (ROCm's vs glibc's), so it gets the 8-bit bar: equal, except a stated handful of values one step apart."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import acgpathtracing_amd as pt
+from acgpathtracing_amd import _native
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = np.load(os.path.join(HERE, "golden", "reference_vectors.npz"))
+
+
+@pytest.fixture(scope="module")
+def ctx(built):
+    state = pt.PathTracerState()
+    pt.createDeviceContext(state, 0)
+    yield state.context
+    _native.hip().pt_destroy(state.context)
+
+
+def run(ctx, op, inp, n, out):
+    inp = np.ascontiguousarray(inp)
+    L = _native.hip()
+    assert L.pt_selftest(ctx, op, inp.ctypes.data, n, out.ctypes.data) == 0, L.pt_last_error(ctx)
+    return out
+
+
+def same_bits_or_both_nan(a, b):
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    return bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))))
+
+
+def test_gpu_tea4_and_lcg_bit_exact(ctx):
+    pairs = np.ascontiguousarray(G["tea_in"], np.uint32)
+    got = run(ctx, 0, pairs, pairs.shape[0], np.zeros(pairs.shape[0], np.uint32))
+    assert np.array_equal(got, G["tea_out"])
+    ka = run(ctx, 0, np.array([[0, 0], [12345, 7]], np.uint32), 2, np.zeros(2, np.uint32))
+    assert ka.tolist() == [1576399551, 1964180806]                       # SURVEY.md §8c known answers
+    for seed, st, va in zip(G["rnd_seeds"], G["rnd_states"], G["rnd_values"]):
+        out = run(ctx, 1, np.array([int(seed), st.size], np.uint32), 1, np.zeros(2 * st.size, np.uint32))
+        assert np.array_equal(out[:st.size], st)
+        assert np.array_equal(out[st.size:], np.ascontiguousarray(va, np.float32).view(np.uint32))
+
+
+def test_gpu_vec_math_and_refract_bit_exact(ctx):
+    A, B, Cc, S = G["vec_a"], G["vec_b"], G["vec_c"], G["vec_s"]
+    n = A.shape[0]
+    rec = np.concatenate([A, B, Cc, S.reshape(-1, 1)], axis=1).astype(np.float32)
+    for op, name in enumerate(["normalize", "reflect", "faceforward", "lerp", "cross", "divide"]):
+        got = run(ctx, 3 + op, rec, n, np.zeros((n, 3), np.float32))
+        assert same_bits_or_both_nan(got, G["vec_" + name]), name
+    m = G["refract_i"].shape[0]
+    rec = np.concatenate([G["refract_i"], G["refract_n"], G["refract_ior"].reshape(-1, 1)], axis=1).astype(np.float32)
+    out = run(ctx, 9, rec, m, np.zeros((m, 4), np.float32))
+    ok = out[:, 3].view(np.uint32) != 0
+    assert np.array_equal(ok, G["refract_ok"] != 0)
+    assert same_bits_or_both_nan(out[ok, :3], G["refract_r"][ok])       # r is only defined when refraction happens
+
+
+def test_gpu_make_color(ctx):
+    c = np.ascontiguousarray(G["color_in"], np.float32)
+    got = run(ctx, 2, c, c.shape[0], np.zeros(c.shape[0], np.uint32)).view(np.uint8).reshape(-1, 4)
+    want = G["color_out"]
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1, "sRGB quantisation more than one step from the reference"
+    assert (d != 0).mean() < 2e-3, "fraction of channels one step apart: %.2e" % (d != 0).mean()
+    assert np.all(got[:, 3] == 255)
+    ka = run(ctx, 2, np.array([[0, 0.18, 1.5]], np.float32), 1, np.zeros(1, np.uint32)).view(np.uint8)
+    assert tuple(ka) == (0, 118, 255, 255)
+
+
+def test_gpu_work_distribution_exact(ctx):
+    off = 0
+    for (world, w, h), ns in zip(G["wd_cases"], G["wd_num_samples"]):
+        m = G["wd_maps"][off:off + world * ns * 2].reshape(world, ns, 2); off += world * ns * 2
+        for r in range(world):
+            q = np.zeros((ns, 4), np.int32); q[:, 0] = world; q[:, 1] = w; q[:, 2] = r; q[:, 3] = np.arange(ns)
+            got = run(ctx, 10, q, ns, np.zeros((ns, 2), np.int32))
+            assert np.array_equal(got, m[r].astype(np.int32)), (world, w, h, r)
