@@ -146,25 +146,59 @@ __device__ __forceinline__ void write_pixel(const RenderArgs& A, const LanePixel
 }
 
 // chunked / batched launches: for every pixel of this rank and every sub-frame in frame order, sum the partial
-// sums in chunk order and blend the sub-frame in — the arithmetic n_frames separate launches would do
-__global__ void k_finalize(const RenderArgs A)
+// sums in chunk order and blend the sub-frame in — the arithmetic n_frames separate launches would do.
+// A workgroup owns 256 consecutive pixels of the rank's tile order.  The partial sums of one pixel are
+// 2^sub_shift float4 in a row, one pixel's row far from the next, so a thread reading its own row would touch one
+// 16-byte piece of 64 different lines per load.  Instead the workgroup fetches, per sub-frame, groups of up to 8 chunks
+// for all its pixels with consecutive threads on consecutive addresses (whole 128-byte runs), parks them in LDS, and
+// each thread then adds its pixel's values from there in chunk order.
+constexpr uint32_t kFinThreads = 256, kFinGroup = 8;
+__global__ void __launch_bounds__(kFinThreads) k_finalize(const RenderArgs A)
 {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= (A.total_samples >> A.sub_shift)) return;
-    int x, y;
-    sample_pixel(A.world, (int)A.width, A.rank, (int)slot, x, y);
-    if ((uint32_t)x >= A.width || (uint32_t)y >= A.height) return;
-    const uint32_t pix = (uint32_t)y * A.width + (uint32_t)x;
+    __shared__ uint32_t s_pix[kFinThreads];
+    __shared__ float4 s_tile[kFinThreads * (kFinGroup + 1)];          // one float4 of padding per pixel row
+    const uint32_t t = threadIdx.x;
+    const uint32_t slot = blockIdx.x * kFinThreads + t;
+    const uint32_t n_slots = A.total_samples >> A.sub_shift;
+    uint32_t pix = 0xFFFFFFFFu;
+    if (slot < n_slots) {
+        int x, y;
+        sample_pixel(A.world, (int)A.width, A.rank, (int)slot, x, y);
+        if ((uint32_t)x < A.width && (uint32_t)y < A.height) pix = (uint32_t)y * A.width + (uint32_t)x;
+    }
+    s_pix[t] = pix;
+    const uint32_t chunks = 1u << A.chunk_shift;
+    const uint32_t grp = chunks < kFinGroup ? chunks : kFinGroup;     // chunks per staging round (a power of two)
+    const uint32_t grp_shift = A.chunk_shift < 3u ? A.chunk_shift : 3u;
     f3 accum = mk(0.0f);
-    if (A.frame > 0u) { const float4 q = A.accum[pix]; accum = mk(q.x, q.y, q.z); }
+    if (pix != 0xFFFFFFFFu && A.frame > 0u) { const float4 q = A.accum[pix]; accum = mk(q.x, q.y, q.z); }
+    __syncthreads();
     for (uint32_t f = 0; f < A.n_frames; f++) {
-        const float4* p = A.partial + ((size_t)pix << A.sub_shift) + ((size_t)f << A.chunk_shift);
-        f3 sum = mk(p[0].x, p[0].y, p[0].z);
-        for (uint32_t k = 1; k < (1u << A.chunk_shift); k++) sum += mk(p[k].x, p[k].y, p[k].z);
+        f3 sum = mk(0.0f);
+        for (uint32_t k0 = 0; k0 < chunks; k0 += grp) {
+            // stage: element e = (pixel p of the workgroup, chunk k0 + k), consecutive e on consecutive threads
+            for (uint32_t e = t; e < kFinThreads * grp; e += kFinThreads) {
+                const uint32_t p = e >> grp_shift, k = e & (grp - 1u);
+                const uint32_t pp = s_pix[p];
+                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (pp != 0xFFFFFFFFu) v = A.partial[((size_t)pp << A.sub_shift) + ((size_t)f << A.chunk_shift) + k0 + k];
+                s_tile[p * (kFinGroup + 1) + k] = v;
+            }
+            __syncthreads();
+            if (pix != 0xFFFFFFFFu) {
+                const float4* row = s_tile + t * (kFinGroup + 1);
+                uint32_t k = 0;
+                if (k0 == 0u) { sum = mk(row[0].x, row[0].y, row[0].z); k = 1; }      // the chain starts at chunk 0, not at zero
+                for (; k < grp; k++) sum += mk(row[k].x, row[k].y, row[k].z);
+            }
+            __syncthreads();
+        }
         accum = blend_frame(accum, sum, A.spp, A.frame + f);
     }
-    A.accum[pix] = make_float4(accum.x, accum.y, accum.z, 1.0f);
-    if (A.fb) A.fb[pix] = make_color(accum);
+    if (pix != 0xFFFFFFFFu) {
+        A.accum[pix] = make_float4(accum.x, accum.y, accum.z, 1.0f);
+        if (A.fb) A.fb[pix] = make_color(accum);
+    }
 }
 
 __device__ __forceinline__ ShadeConsts shade_consts(const RenderArgs& A)
@@ -609,7 +643,7 @@ hipError_t launch_items(const RenderArgs& args, hipStream_t stream)
 hipError_t launch_finalize(const RenderArgs& args, hipStream_t stream)
 {
     const uint32_t slots = args.total_samples >> args.sub_shift;
-    k_finalize<<<(slots + 255) / 256, 256, 0, stream>>>(args);
+    k_finalize<<<(slots + kFinThreads - 1) / kFinThreads, kFinThreads, 0, stream>>>(args);
     return hipGetLastError();
 }
 
