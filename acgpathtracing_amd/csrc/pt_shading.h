@@ -132,7 +132,9 @@ struct Pending {
 
 // __closesthit__diffuse__ch, pathTracerPrograms.cu:866-1031, for one lane.  Returns true when a
 // shadow ray (P, L, 0.01, Ldist - 0.01) has to be traced before the segment can be accounted.
-// TRIG_DIAG (timing experiment only): replaces sinf/cosf/acosf by hardware approximations to price them.
+// TRIG_DIAG (kernel variant 10, opt-in): the cosine-weighted sampler with v_sin_f32 / v_cos_f32 and sqrt(1 - z1) for
+// sin(acos(sqrt(z1))) — the kind of arithmetic the reference's own build uses (nvcc --use_fast_math, CMakeLists.txt:267).
+// Different low bits than the default path, same image within the parity tolerance (test_fast_math_variant).
 template <bool TRIG_DIAG = false>
 __device__ __forceinline__ bool shade_hit(const DeviceScene& sc, const ShadeConsts& K, const f3& org, const f3& dir,
                                           float t_hit, int slot, int depth, uint32_t& pseed, f3& att, f3& emission,

@@ -352,8 +352,8 @@ k_render_pw(const RenderArgs A)
     unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0;
     unsigned long long n_steps = 0, n_lane_steps = 0, n_rounds = 0, n_lane_rounds = 0;
     // STATS only: 100 MHz stamps of this wave's start, of the moment it found the queue empty, and of its end
-    unsigned long long t_start = 0, t_drain = 0;
-    if (STATS) t_start = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t_start = 0, t_drain = 0, t_phase = 0, t_in_shade = 0;
+    if (STATS) { t_start = __builtin_amdgcn_s_memrealtime(); t_phase = t_start; }
 
     LanePixel lp; lp.alive = false; lp.new_path = false; lp.pix = lp.px = lp.py = lp.seed = lp.samples_left = lp.chunk = 0; lp.result = mk(0.0f);
     uint32_t pseed = 0;
@@ -371,7 +371,7 @@ k_render_pw(const RenderArgs A)
 
     for (;;) {
         // =========================== shade / regenerate: lanes with no ray in flight ===============
-        if (STATS) { n_rounds += 1; n_lane_rounds += (unsigned long long)__popcll(__ballot(lp.alive && node == kSentinel)); }
+        if (STATS) { n_rounds += 1; n_lane_rounds += (unsigned long long)__popcll(__ballot(lp.alive && node == kSentinel)); t_phase = __builtin_amdgcn_s_memrealtime(); }
         bool segment_done = false, started_shadow = false;
         f3 emission = mk(0.0f);
         if (lp.alive && node == kSentinel) {
@@ -450,6 +450,7 @@ k_render_pw(const RenderArgs A)
         }
         n_radiance += (unsigned long long)__popcll(__ballot(start_radiance));
 
+        if (STATS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); t_in_shade += now - t_phase; t_phase = now; }
         // =========================== traversal: until SHADE_K lanes are parked =====================
         for (;;) {
             const bool act = node != kSentinel;
@@ -622,6 +623,7 @@ k_render_pw(const RenderArgs A)
             if (w < kMaxTimedWaves) {
                 A.counters[8 + 3 * w] = t_start;
                 A.counters[8 + 3 * w + 1] = t_drain;
+                atomicAdd(&A.counters[8 + 3 * kMaxTimedWaves + 2048], t_in_shade);       // 10 ns units, summed over waves
                 A.counters[8 + 3 * w + 2] = __builtin_amdgcn_s_memrealtime();
             }
         }
@@ -971,7 +973,7 @@ static const VariantDesc kVariants[] = {
     {k_render_pw<48, 8, 2, 1024, 4, false, 0, 1>, 1024, 2, "pw K48 L8 q16 nodes in LDS, 1024 threads"},
     {k_render_pw<48, 8, 0, 256, 4, false, 1, 1>, 256, 0, "DIAG +12 VALU per inner step"},
     {k_render_pw<48, 8, 0, 256, 4, false, 2, 1>, 256, 0, "DIAG +2 loads per inner step"},
-    {k_render_pw<48, 8, 0, 256, 4, false, 3, 1>, 256, 0, "DIAG hardware sin/cos, algebraic acos (wrong bits, timing only)"},
+    {k_render_pw<48, 12, 0, 256, 4, false, 3, 1>, 256, 0, "FAST-MATH hardware sin/cos + algebraic acos in the cosine-weighted sampler (opt-in; other bits than the default)"},
     {k_render_pw<48, 8, 3, 256, 4, false, 0, 1>, 256, 3, "pw K48 L8 four-wide 8-bit nodes w4"},
     {k_render_pw<48, 8, 3, 256, 4, true, 0, 1>, 256, 3, "four-wide + scheduler stats"},
     {k_render_pw<48, 16, 3, 256, 4, false, 0, 1>, 256, 3, "pw K48 L16 four-wide"},

@@ -255,7 +255,7 @@ def test_every_kernel_variant_gives_the_same_bits(full):
             name = L.pt_variant_name(v)
             if name is None:
                 break
-            if name.startswith(b"DIAG") or L.pt_set_tuning(state.context, 0, v) != 0:
+            if name.startswith(b"DIAG") or name.startswith(b"FAST-MATH") or L.pt_set_tuning(state.context, 0, v) != 0:
                 continue
             acc, fb, st = _gpu_render(state, p)
             tried += 1
@@ -268,6 +268,28 @@ def test_every_kernel_variant_gives_the_same_bits(full):
     finally:
         assert L.pt_set_tuning(state.context, 0, _DEFAULT_VARIANT) == 0
     assert tried >= 4
+
+
+def test_fast_math_variant(full):
+    """Kernel variant 10 (opt-in): hardware sin / cos and an algebraic sin(acos(.)) in the cosine-weighted sampler, as
+    the reference's --use_fast_math build would use.  Not bit-identical to the default, but the same image within the
+    parity tolerance against the oracle, and the same number of camera paths."""
+    state, obj, sc = full
+    L = _native.hip()
+    v = [i for i in range(64) if (L.pt_variant_name(i) or b"").startswith(b"FAST-MATH")]
+    assert len(v) == 1
+    p = make_params(160, 96, 32, 8, True, True)
+    base, _, st0 = _gpu_render(state, p)
+    try:
+        assert L.pt_set_tuning(state.context, 0, v[0]) == 0
+        fast, _, st1 = _gpu_render(state, p)
+    finally:
+        assert L.pt_set_tuning(state.context, 0, _DEFAULT_VARIANT) == 0
+    ref, _, _, _ = sc.render(copy_params(p), use_bvh=True)
+    assert st1[0].paths == st0[0].paths
+    assert image_mse(fast, ref) < MSE_TOL and image_mse(fast, base) < MSE_TOL
+    assert not np.array_equal(fast.view(np.uint32), base.view(np.uint32))
+    print("fast-math variant: MSE vs oracle %.3e (default %.3e)" % (image_mse(fast, ref), image_mse(base, ref)))
 
 
 @pytest.mark.parametrize("chunks", [2, 8, 32, 0])
