@@ -37,7 +37,7 @@ __host__ __device__ inline float ord2f(uint32_t u)
 __global__ void k_prepare(const float4* __restrict__ verts, const uint32_t* __restrict__ idx,
                           const uint32_t* __restrict__ mat_ids, uint32_t n_tris,
                           TriRecord* __restrict__ tri_unsorted, float4* __restrict__ tri_lo, float4* __restrict__ tri_hi,
-                          uint32_t* __restrict__ scene_bounds /*6 ordered uints: lo xyz, hi xyz*/)
+                          uint32_t* __restrict__ scene_bounds /*6 ordered uints: lo xyz, hi xyz*/, float pad_abs)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -52,8 +52,10 @@ __global__ void k_prepare(const float4* __restrict__ verts, const uint32_t* __re
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             float l = fminf(pa[k], fminf(pb[k], pc[k])), h = fmaxf(pa[k], fmaxf(pb[k], pc[k]));
-            // pad: the triangle test accepts rays a few ulps outside the exact triangle
-            float pad = 1e-5f * fmaxf(1.0f, fmaxf(fabsf(l), fabsf(h)));
+            // pad: the triangle test accepts rays a few ulps outside the exact triangle (relative term), and the render
+            // kernel's slab test t = p * (1/d) - o/d rounds -o/d once, i.e. moves a plane by up to |o| * 2^-24; pad_abs =
+            // 2^-19 of the largest |coordinate| of the scene covers that for ray origins up to 32 scene sizes away
+            float pad = fmaxf(1e-5f * fmaxf(1.0f, fmaxf(fabsf(l), fabsf(h))), pad_abs);
             lo[k] = l - pad; hi[k] = h + pad;
         }
         tri_lo[i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
@@ -475,6 +477,10 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
     float4 root_hi;
     int cur = 0;
 
+    float coord_max = 1.0f;
+    for (size_t i = 0; i < n_verts; i++)
+        for (int k = 0; k < 3; k++) { const float a = fabsf(h_verts_xyzw[4 * i + k]); if (a > coord_max && a < INFINITY) coord_max = a; }
+    const float pad_abs = coord_max * (1.0f / 524288.0f);
     HIPCK(sc.alloc(&d_verts, n_verts * 16));
     HIPCK(sc.alloc(&d_idx, (size_t)n * 12));
     HIPCK(sc.alloc(&d_mat, (size_t)n * 4));
@@ -505,7 +511,7 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
     HIPCK(hipEventCreate(&sc.ev1));
     HIPCK(hipEventRecord(sc.ev0, stream));
 
-    k_prepare<<<blocks, 256, 0, stream>>>(d_verts, d_idx, d_mat, n, d_unsorted, d_tlo, d_thi, d_bounds);
+    k_prepare<<<blocks, 256, 0, stream>>>(d_verts, d_idx, d_mat, n, d_unsorted, d_tlo, d_thi, d_bounds, pad_abs);
     k_morton<<<blocks, 256, 0, stream>>>(d_tlo, d_thi, n, d_bounds, d_keys[0], d_vals[0]);
     for (int pass = 0; pass < 4; pass++) {
         const int shift = 8 * pass;

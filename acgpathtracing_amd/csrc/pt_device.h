@@ -169,6 +169,11 @@ __device__ __forceinline__ bool tri_test_lazy(const f3& o, const f3& d, const f3
 
 // 1-ulp reciprocal (v_rcp_f32) for quantities outside the bit-exact contract (box tests).
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// The same, kept finite: the fma form of the slab test, t = p * (1/d) - o/d, must not see inf - inf for a box that
+// straddles a coordinate plane when d is 0 (the subtract-then-multiply form gets -inf / +inf there and is fine).  With
+// +-1e30 a zero direction component still sends both planes to +-huge with the signs of (p - o), up to the rounding of
+// o/d that lbvh_build.hip's pad_abs covers.
+__device__ __forceinline__ float finite_rcp(float x) { return fminf(fmaxf(__builtin_amdgcn_rcpf(x), -1e30f), 1e30f); }
 
 // ------------------------------------------------------------ LDS lane stack ----
 // One stack per lane, entry-major / lane-minor so a wave-wide push or pop touches 64

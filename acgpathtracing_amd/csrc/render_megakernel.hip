@@ -312,7 +312,9 @@ k_render(const RenderArgs A)
 // image is bit-identical to variant 0; only the interleaving between lanes changes.
 // LEAF_K: triangle tests run when at least LEAF_K lanes sit at a leaf, or no lane has an inner node.
 // =================================================================================================
-// NODE_FMT: 0 = fp32 boxes, 64-byte nodes in global memory (4 x 16-byte loads per visit)
+// NODE_FMT: 0 = fp32 boxes, 64-byte nodes in global memory (4 x 16-byte loads per visit), slab test as one fma per plane
+//           5 = the same nodes, slab test as subtract + multiply per plane
+//           4 = 16-bit grid nodes with the fma form
 //           1 = 16-bit grid boxes, 32-byte nodes in global memory (2 loads per visit)
 //           2 = the same 32-byte nodes staged into LDS by each workgroup (scenes whose node array
 //               fits beside the lane stacks; 1024-thread workgroups so one copy serves 16 waves)
@@ -389,10 +391,13 @@ k_render_pw(const RenderArgs A)
                 }
                 lp.result += emission;                                // :760 (before the radiance term)
                 if (want_shadow) {
-                    ro = P; rd = L; rinv = mk(fast_rcp(L.x), fast_rcp(L.y), fast_rcp(L.z));
-                    if (NODE_FMT == 1 || NODE_FMT == 2) {
+                    ro = P; rd = L;
+                    rinv = NODE_FMT == 0 ? mk(finite_rcp(L.x), finite_rcp(L.y), finite_rcp(L.z)) : mk(fast_rcp(L.x), fast_rcp(L.y), fast_rcp(L.z));
+                    if (NODE_FMT == 0) gro = mk(-(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z));
+                    if (NODE_FMT == 1 || NODE_FMT == 2 || NODE_FMT == 4) {
                         gro = mk((ro.x - G.ox) * G.icx, (ro.y - G.oy) * G.icy, (ro.z - G.oz) * G.icz);
                         rinv = mk(G.cx * rinv.x, G.cy * rinv.y, G.cz * rinv.z);
+                        if (NODE_FMT == 4) gro = mk(-(gro.x * rinv.x), -(gro.y * rinv.y), -(gro.z * rinv.z));   // t = q * rinv + gro
                     }
                     rtmin = 0.01f; rtmax = Ldist - 0.01f; best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu;
                     node = root; sp = 0; cur_list = 0u; shadow_ray = true; shadow_hit = false; started_shadow = true;
@@ -440,10 +445,12 @@ k_render_pw(const RenderArgs A)
             start_radiance = true;
         }
         if (start_radiance) {                                         // traceRadiance :750-757
-            rinv = mk(fast_rcp(rd.x), fast_rcp(rd.y), fast_rcp(rd.z));
-            if (NODE_FMT == 1 || NODE_FMT == 2) {
+            rinv = NODE_FMT == 0 ? mk(finite_rcp(rd.x), finite_rcp(rd.y), finite_rcp(rd.z)) : mk(fast_rcp(rd.x), fast_rcp(rd.y), fast_rcp(rd.z));
+            if (NODE_FMT == 0) gro = mk(-(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z));
+            if (NODE_FMT == 1 || NODE_FMT == 2 || NODE_FMT == 4) {
                 gro = mk((ro.x - G.ox) * G.icx, (ro.y - G.oy) * G.icy, (ro.z - G.oz) * G.icz);
                 rinv = mk(G.cx * rinv.x, G.cy * rinv.y, G.cz * rinv.z);
+                if (NODE_FMT == 4) gro = mk(-(gro.x * rinv.x), -(gro.y * rinv.y), -(gro.z * rinv.z));
             }
             rtmin = 0.01f; rtmax = 1e16f; best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu;
             node = root; sp = 0; cur_list = 0u; shadow_ray = false;
@@ -501,7 +508,7 @@ k_render_pw(const RenderArgs A)
             }
             if (act && node >= 0) {
                 float n0, f0, n1, f1; int c0, c1;
-                if (NODE_FMT == 0) {
+                if (NODE_FMT == 5) {        // the two-step slab test (p - o) * (1/d): comparison variant
                     const BvhNode* np = sc.nodes + node;
                     const float4 a = np->a, b = np->b, c = np->c;
                     const int4 ch = np->d;
@@ -514,6 +521,39 @@ k_render_pw(const RenderArgs A)
                     float u0 = (b.z - ro.x) * rinv.x, u1 = (c.y - ro.x) * rinv.x;
                     float v0 = (b.w - ro.y) * rinv.y, v1 = (c.z - ro.y) * rinv.y;
                     float w0 = (c.x - ro.z) * rinv.z, w1 = (c.w - ro.z) * rinv.z;
+                    n1 = fmaxf(fmaxf(fminf(u0, u1), fminf(v0, v1)), fmaxf(fminf(w0, w1), rtmin));
+                    f1 = fminf(fminf(fmaxf(u0, u1), fmaxf(v0, v1)), fmaxf(w0, w1)) * kFarWiden;
+                } else if (NODE_FMT == 0) {
+                    // fp32 nodes, slab planes as one full-rate fma each: t = p * (1/d) + (-o/d); lbvh_build.hip's pad_abs
+                    // covers the single rounding of -o/d
+                    const BvhNode* np = sc.nodes + node;
+                    const float4 a = np->a, b = np->b, c = np->c;
+                    const int4 ch = np->d;
+                    c0 = ch.x; c1 = ch.y;
+                    const float x0 = __builtin_fmaf(a.x, rinv.x, gro.x), x1 = __builtin_fmaf(a.w, rinv.x, gro.x);
+                    const float y0 = __builtin_fmaf(a.y, rinv.y, gro.y), y1 = __builtin_fmaf(b.x, rinv.y, gro.y);
+                    const float z0 = __builtin_fmaf(a.z, rinv.z, gro.z), z1 = __builtin_fmaf(b.y, rinv.z, gro.z);
+                    n0 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), rtmin));
+                    f0 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1)) * kFarWiden;
+                    const float u0 = __builtin_fmaf(b.z, rinv.x, gro.x), u1 = __builtin_fmaf(c.y, rinv.x, gro.x);
+                    const float v0 = __builtin_fmaf(b.w, rinv.y, gro.y), v1 = __builtin_fmaf(c.z, rinv.y, gro.y);
+                    const float w0 = __builtin_fmaf(c.x, rinv.z, gro.z), w1 = __builtin_fmaf(c.w, rinv.z, gro.z);
+                    n1 = fmaxf(fmaxf(fminf(u0, u1), fminf(v0, v1)), fmaxf(fminf(w0, w1), rtmin));
+                    f1 = fminf(fminf(fmaxf(u0, u1), fmaxf(v0, v1)), fmaxf(w0, w1)) * kFarWiden;
+                } else if (NODE_FMT == 4) {
+                    // 16-bit grid nodes, one conversion + one fma per plane (the grid's one-cell outward rounding covers the
+                    // fma form's error, which is below 0.01 cell)
+                    const QNode* np = sc.qnodes + node;
+                    const uint4 qa = np->a, qb = np->b;
+                    c0 = (int)qa.w; c1 = (int)qb.w;
+                    const float x0 = __builtin_fmaf((float)(qa.x & 0xFFFFu), rinv.x, gro.x), x1 = __builtin_fmaf((float)(qa.y >> 16), rinv.x, gro.x);
+                    const float y0 = __builtin_fmaf((float)(qa.x >> 16), rinv.y, gro.y), y1 = __builtin_fmaf((float)(qa.z & 0xFFFFu), rinv.y, gro.y);
+                    const float z0 = __builtin_fmaf((float)(qa.y & 0xFFFFu), rinv.z, gro.z), z1 = __builtin_fmaf((float)(qa.z >> 16), rinv.z, gro.z);
+                    n0 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), rtmin));
+                    f0 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1)) * kFarWiden;
+                    const float u0 = __builtin_fmaf((float)(qb.x & 0xFFFFu), rinv.x, gro.x), u1 = __builtin_fmaf((float)(qb.y >> 16), rinv.x, gro.x);
+                    const float v0 = __builtin_fmaf((float)(qb.x >> 16), rinv.y, gro.y), v1 = __builtin_fmaf((float)(qb.z & 0xFFFFu), rinv.y, gro.y);
+                    const float w0 = __builtin_fmaf((float)(qb.y & 0xFFFFu), rinv.z, gro.z), w1 = __builtin_fmaf((float)(qb.z >> 16), rinv.z, gro.z);
                     n1 = fmaxf(fmaxf(fminf(u0, u1), fminf(v0, v1)), fmaxf(fminf(w0, w1), rtmin));
                     f1 = fminf(fminf(fmaxf(u0, u1), fmaxf(v0, v1)), fmaxf(w0, w1)) * kFarWiden;
                 } else {
@@ -742,7 +782,7 @@ k_trace_stream(const DeviceScene sc, uint32_t stack_entries, const float4* __res
                     const float4 a = rays[2ull * rid], b = rays[2ull * rid + 1];
                     ro = mk(a.x, a.y, a.z); rd = mk(a.w, b.x, b.y); rtmin = b.z;
                     any_ray = b.w < 0.0f; rtmax = fabsf(b.w);
-                    rinv = mk(fast_rcp(rd.x), fast_rcp(rd.y), fast_rcp(rd.z));
+                    rinv = FMA_SLAB ? mk(finite_rcp(rd.x), finite_rcp(rd.y), finite_rcp(rd.z)) : mk(fast_rcp(rd.x), fast_rcp(rd.y), fast_rcp(rd.z));
                     if (FMA_SLAB) roi = mk(-(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z));
                     best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu; any_hit = false;
                     node = sc.n_tris ? 0 : kSentinel; sp = 0;
@@ -762,7 +802,7 @@ k_trace_stream(const DeviceScene sc, uint32_t stack_entries, const float4* __res
             const float4 a = np->a, b = np->b, c = np->c;
             const int4 ch = np->d;
             float x0, x1, y0, y1, z0, z1, u0, u1, v0, v1, w0, w1;
-            if (FMA_SLAB) {        // experiment: t = p * (1/d) - o/d, one full-rate fma per plane (looser rounding: timing only)
+            if (FMA_SLAB) {        // t = p * (1/d) - o/d, one full-rate fma per plane: the render kernel's form (NODE_FMT 0)
                 x0 = __builtin_fmaf(a.x, rinv.x, roi.x); x1 = __builtin_fmaf(a.w, rinv.x, roi.x);
                 y0 = __builtin_fmaf(a.y, rinv.y, roi.y); y1 = __builtin_fmaf(b.x, rinv.y, roi.y);
                 z0 = __builtin_fmaf(a.z, rinv.z, roi.z); z1 = __builtin_fmaf(b.y, rinv.z, roi.z);
@@ -982,6 +1022,9 @@ static const VariantDesc kVariants[] = {
     {k_render_pw<48, 8, 0, 256, 4, false, 0, 1>, 256, 0, "pw K48 L8 fp32 w4 (kLargeSceneVariant: chosen automatically above 100 k triangles)"},
     {k_render_pw<48, 16, 0, 256, 4, false, 0, 1>, 256, 0, "pw K48 L16 fp32 w4"},
     {k_render_pw<44, 12, 0, 256, 4, false, 0, 1>, 256, 0, "pw K44 L12 fp32 w4"},
+    {k_render_pw<48, 12, 4, 256, 4, false, 0, 1>, 256, 4, "pw K48 L12 q16 nodes, fma decode w4"},
+    {k_render_pw<48, 12, 5, 256, 4, false, 0, 1>, 256, 0, "pw K48 L12 fp32 w4, two-step slab test (p - o) * (1/d) (default until the fma form)"},
+    {k_render_pw<48, 12, 1, 256, 4, false, 0, 1>, 256, 1, "pw K48 L12 q16 nodes w4"},
 };
 int render_variant_count() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
 const char* render_variant_name(int v) { return (v >= 0 && v < render_variant_count()) ? kVariants[v].name : "?"; }

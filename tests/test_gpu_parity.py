@@ -78,7 +78,8 @@ def test_morton_sort_bit_exact(full):
     # restatement of k_prepare / k_morton (fp32 throughout)
     tri = v[idx][:, :, :3]
     lo = tri.min(axis=1); hi = tri.max(axis=1)
-    pad = np.float32(1e-5) * np.maximum(np.float32(1.0), np.maximum(np.abs(lo), np.abs(hi)))
+    pad_abs = np.float32(max(1.0, float(np.abs(v[:, :3]).max()))) * np.float32(1.0 / 524288.0)
+    pad = np.maximum(np.float32(1e-5) * np.maximum(np.float32(1.0), np.maximum(np.abs(lo), np.abs(hi))), pad_abs).astype(np.float32)
     lo = (lo - pad).astype(np.float32); hi = (hi + pad).astype(np.float32)
     slo = lo.min(axis=0); shi = hi.max(axis=0)
     c = (np.float32(0.5) * (lo + hi)).astype(np.float32)
@@ -628,7 +629,7 @@ def test_ray_stream_kernel_bit_exact(full):
     t_ref, prim_ref = sc.trace_closest(np.ascontiguousarray(rays[is_c]), use_bvh=False)
     ar = np.ascontiguousarray(rays[~is_c]); ar[:, 7] *= -1.0
     any_ref = sc.trace_any(ar, use_bvh=False) != 0
-    for fmt in (0, 1):                                       # two-child fp32 tree, four-wide 8-bit tree
+    for fmt in (0, 1, 2):                                    # two-child fp32 tree, four-wide 8-bit tree, two-child with the fma slab test
         t = np.zeros(n, np.float32); prim = np.zeros(n, np.uint32); ms = C.c_float()
         assert L.pt_bench_traversal(state.context, rays.ctypes.data, n, 2, fmt, t.ctypes.data, prim.ctypes.data, C.byref(ms), None) == 0
         assert np.array_equal(prim[is_c], prim_ref) and np.array_equal(t[is_c].view(np.uint32), t_ref.view(np.uint32)), fmt

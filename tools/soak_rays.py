@@ -41,7 +41,7 @@ def main():
             assert L.pt_trace_closest(state.context, rays.ctypes.data, n, t.ctypes.data, p.ctypes.data) == 0
             assert L.pt_trace_any(state.context, rays.ctypes.data, n, h.ctypes.data) == 0
             res = {"query": (t.copy(), p.copy())}
-            for fmt in (0, 1):
+            for fmt in (0, 1, 2):
                 assert L.pt_bench_traversal(state.context, rays.ctypes.data, n, 1, fmt, t.ctypes.data, p.ctypes.data, C.byref(ms), None) == 0
                 res["stream fmt %d" % fmt] = (t.copy(), p.copy())
             t_b, p_b = sc.trace_closest(rays, use_bvh=True)
@@ -56,7 +56,7 @@ def main():
             if m.any():
                 bad += int(m.sum()); print("MISMATCH any-hit mode %d seed %d: %d rays" % (mode, s, int(m.sum())))
             ar = rays.copy(); ar[:, 7] *= -1.0
-            for fmt in (0, 1):
+            for fmt in (0, 1, 2):
                 assert L.pt_bench_traversal(state.context, ar.ctypes.data, n, 1, fmt, t.ctypes.data, p.ctypes.data, C.byref(ms), None) == 0
                 m = (p != 0) != a_ref
                 if m.any():
