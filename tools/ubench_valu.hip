@@ -181,6 +181,26 @@ __global__ void __launch_bounds__(256) NAME(int iters, float* out) { \
     v2f s = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7; if (s.x + s.y == 12345.678f) out[0] = s.x; \
 }
 PKBODY(k_pkfma, "v_pk_fma_f32") PKBODY2(k_pkmul, "v_pk_mul_f32") PKBODY2(k_pkadd, "v_pk_add_f32")
+// 64-bit address arithmetic as the compiler emits it for `base + index * size` (register pairs)
+#define B64BODY(NAME, ASM) \
+__global__ void __launch_bounds__(256) NAME(int iters, float* out) { \
+    unsigned long long r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7; \
+    unsigned long long b = 0x1000; uint32_t m = 48; \
+    for (int i = 0; i < iters; i++) { \
+        _Pragma("unroll") for (int k = 0; k < 8; k++) { \
+            asm volatile(ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7) \
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(b), "v"(m) : "vcc"); \
+        } \
+    } \
+    if (r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 == 12345678ull) out[0] = 1.0f; \
+}
+#define A_SHL64(n)   "v_lshlrev_b64 %" #n ", 6, %" #n "\n"
+#define A_LSHLADD64(n) "v_lshl_add_u64 %" #n ", %" #n ", 0, %8\n"
+#define A_MAD64(n)   "v_mad_u64_u32 %" #n ", vcc, %9, 48, %" #n "\n"
+B64BODY(k_shl64, A_SHL64) B64BODY(k_lshladd64, A_LSHLADD64) B64BODY(k_mad64, A_MAD64)
+#define A_MUL24(n) "v_mul_u32_u24 %" #n ", %" #n ", %10\n"
+#define A_MULLO(n) "v_mul_lo_u32 %" #n ", %" #n ", %10\n"
+BODY(k_mul24, A_MUL24) BODY(k_mullo, A_MULLO)
 // scalar: s_and_b64 / s_bcnt1 chain next to nothing else
 __global__ void __launch_bounds__(256) k_salu(int iters, float* out) {
     unsigned long long x = 0x123456789ull + blockIdx.x; uint32_t c = 0;
@@ -207,6 +227,7 @@ int main()
                        {"v_cndmask (sgpr pair, set)", k_cnd_s}, {"v_cndmask (vcc from v_cmp)", k_cnd_init}, {"v_cmp + v_cndmask PAIR", k_cmp_cnd},
                        {"1 v_cmp vcc + 4 v_cndmask (x0.2)", k_cmp_cnd4}, {"1 v_cmp sgpr + 4 v_cndmask (x0.2)", k_cmps_cnd4}, {"1 v_cmp vcc + 4 cndmask_e64 vcc", k_cmp_cnd4_e64}, {"1 v_cmp vcc + 4 cndmask dst!=src", k_cmp_cnd4_d},
                        {"v_pk_fma_f32 (2 fma)", k_pkfma}, {"v_pk_mul_f32 (2 mul)", k_pkmul}, {"v_pk_add_f32 (2 add)", k_pkadd},
+                       {"v_lshlrev_b64", k_shl64}, {"v_lshl_add_u64", k_lshladd64}, {"v_mad_u64_u32", k_mad64}, {"v_mul_u32_u24", k_mul24}, {"v_mul_lo_u32", k_mullo},
                        {"v_bfi_b32", k_bfi}, {"v_min3_f32", k_min3}, {"v_sub_f32", k_sub}, {"v_xor_b32", k_xor}, {"v_mad_u32_u24", k_mad24}, {"v_rcp_f32", k_rcp}, {"v_mov_b32", k_mov}, {"v_lshl_or_b32", k_lshlor}, {"v_and_or_b32", k_andor}, {"s_and_b64 (scalar)", k_salu}};
     const int iters = 2000;
     printf("%-26s %10s %10s %10s %10s   SIMD cycles per wave-instruction\n", "instruction", "1 w/SIMD", "2 w/SIMD", "4 w/SIMD", "8 w/SIMD");
