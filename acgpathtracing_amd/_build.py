@@ -18,7 +18,7 @@ HIP_SOURCES = ["capi.hip", "lbvh_build.hip", "wide_bvh.hip", "render_megakernel.
 HIP_HEADERS = ["pt_device.h", "pt_shading.h", "lbvh_build.h", "render_megakernel.h", "selftest.h"]
 HOST_SOURCES = ["host_capi.cpp", "TinyObjWrapper.cpp", "Camera.cpp", "Trackball.cpp", "ImageIO.cpp"]
 
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-fvisibility=hidden", "-std=c++17"]
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-fvisibility=hidden", "-std=c++17"]
 HOST_FLAGS = ["-O2", "-std=c++14", "-fPIC", "-shared", "-ffp-contract=off", "-fvisibility=hidden", "-pthread"]
 
 

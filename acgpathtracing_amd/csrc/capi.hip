@@ -147,7 +147,8 @@ PT_API int pt_set_scene(pt_ctx* c, const float* verts_xyzw, size_t n_verts, cons
 {
     if (!c) return fail(nullptr, "pt_set_scene: null context");
     if (n_tris > 0 && (!verts_xyzw || !idx || !mat_ids || !mats)) return fail(c, "pt_set_scene: null array");
-    if (n_tris >= 0x7FFFFFFEull || n_verts >= 0xFFFFFFFFull) return fail(c, "pt_set_scene: too many triangles or vertices");
+    // the render kernel addresses nodes (64 B) and triangle records (48 B) with 32-bit byte offsets
+    if (n_tris >= (1ull << 26) || n_verts >= 0xFFFFFFFFull) return fail(c, "pt_set_scene: too many triangles (limit 2^26) or vertices");
     for (size_t i = 0; i < 3 * n_tris; i++)
         if (idx[i] >= n_verts) return fail(c, "pt_set_scene: vertex index out of range");
     for (size_t i = 0; i < n_tris; i++)

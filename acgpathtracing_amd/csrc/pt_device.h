@@ -175,6 +175,13 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 // o/d that lbvh_build.hip's pad_abs covers.
 __device__ __forceinline__ float finite_rcp(float x) { return fminf(fmaxf(__builtin_amdgcn_rcpf(x), -1e30f), 1e30f); }
 
+// ------------------------------------------------------------ wave votes ----
+// __ballot(int) first turns the predicate into 0 / 1 in a VGPR and compares it again (two half-rate vector
+// instructions per vote); the lane mask of a bool is already there.  Counts are taken as int so that the
+// comparison with a threshold stays on the scalar unit (the 64-bit form is a vector compare).
+__device__ __forceinline__ unsigned long long vote(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ int popc(unsigned long long m) { return __builtin_popcount((uint32_t)m) + __builtin_popcount((uint32_t)(m >> 32)); }
+
 // ------------------------------------------------------------ LDS lane stack ----
 // One stack per lane, entry-major / lane-minor so a wave-wide push or pop touches 64
 // consecutive dwords (conflict-free ds_read_b32 / ds_write_b32).

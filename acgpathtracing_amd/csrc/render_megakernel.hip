@@ -69,11 +69,11 @@ struct LanePixel {
 template <bool STATS = false>
 __device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q, uint32_t lane, unsigned long long below, LanePixel& lp)
 {
-    unsigned long long idle = __ballot(!lp.alive);
+    unsigned long long idle = vote(!lp.alive);
     while (idle != 0ull && (q.res_count != 0u || q.shards_left != 0u)) {
         if (q.res_count == 0u) {                                      // wave-uniform: fetch a grant
             const uint32_t leader = (uint32_t)__ffsll((long long)idle) - 1u;
-            const uint32_t idle_n = (uint32_t)__popcll(idle);
+            const uint32_t idle_n = (uint32_t)popc(idle);
             const uint32_t req = idle_n > A.grant ? idle_n : A.grant;   // at least what is needed now
             uint32_t base = 0;
             if (lane == leader) base = atomicAdd(&A.queue_heads[q.shard], req);
@@ -94,9 +94,9 @@ __device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q,
             q.res_first = first; q.res_count = avail;
             if (avail == 0u) continue;
         }
-        const uint32_t want = (uint32_t)__popcll(idle);
+        const uint32_t want = (uint32_t)popc(idle);
         const uint32_t take = want < q.res_count ? want : q.res_count;
-        const uint32_t rank = (uint32_t)__popcll(idle & below);
+        const uint32_t rank = (uint32_t)popc(idle & below);
         if (!lp.alive && rank < take) {
             const uint32_t item = q.res_first + rank;
             const uint2 it = A.items[item];
@@ -112,7 +112,7 @@ __device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q,
             }
         }
         q.res_first += take; q.res_count -= take;
-        idle = __ballot(!lp.alive);          // lanes that drew a padding item try again
+        idle = vote(!lp.alive);          // lanes that drew a padding item try again
     }
 }
 
@@ -237,7 +237,7 @@ k_render(const RenderArgs A)
 
     for (;;) {
         refill_lanes(A, q, lane, below, lp);
-        const unsigned long long live = __ballot(lp.alive);
+        const unsigned long long live = vote(lp.alive);
         if (live == 0ull) { if (q.shards_left == 0u && q.res_count == 0u) break; else continue; }
 
         if (lp.alive && lp.new_path) {                                // camera path start, :727-745
@@ -255,7 +255,7 @@ k_render(const RenderArgs A)
 
         HitRec hit;                                                   // radiance segment (:750-757)
         traverse<false>(sc, st, lp.alive, org, dir, 0.01f, 1e16f, hit);
-        n_radiance += (unsigned long long)__popcll(live);
+        n_radiance += (unsigned long long)popc(live);
 
         f3 emission = mk(0.0f), P = mk(0.0f), L = mk(0.0f);
         float Ldist = 0.0f;
@@ -265,11 +265,11 @@ k_render(const RenderArgs A)
         if (lp.alive && hit.slot >= 0)
             want_shadow = shade_hit(sc, K, org, dir, hit.t, hit.slot, depth, pseed, att, emission, pd, P, L, Ldist);
 
-        const unsigned long long shadow_mask = __ballot(want_shadow);
+        const unsigned long long shadow_mask = vote(want_shadow);
         if (shadow_mask != 0ull) {                                    // traceOcclusion :651-684
             HitRec sh;
             const bool occluded = traverse<true>(sc, st, want_shadow, P, L, 0.01f, Ldist - 0.01f, sh);
-            n_shadow += (unsigned long long)__popcll(shadow_mask);
+            n_shadow += (unsigned long long)popc(shadow_mask);
             if (want_shadow && !occluded) pd.radiance += K.Le * pd.weight;
         }
 
@@ -291,8 +291,8 @@ k_render(const RenderArgs A)
                 if (lp.samples_left == 0u) { write_pixel(A, lp); lp.alive = false; finished = true; }
             }
         }
-        n_paths += (unsigned long long)__popcll(__ballot(end));
-        n_pixels += (unsigned long long)__popcll(__ballot(finished));
+        n_paths += (unsigned long long)popc(vote(end));
+        n_pixels += (unsigned long long)popc(vote(finished));
     }
     if (lane == 0) {
         atomicAdd(&A.counters[0], n_radiance);
@@ -373,7 +373,7 @@ k_render_pw(const RenderArgs A)
 
     for (;;) {
         // =========================== shade / regenerate: lanes with no ray in flight ===============
-        if (STATS) { n_rounds += 1; n_lane_rounds += (unsigned long long)__popcll(__ballot(lp.alive && node == kSentinel)); t_phase = __builtin_amdgcn_s_memrealtime(); }
+        if (STATS) { n_rounds += 1; n_lane_rounds += (unsigned long long)popc(vote(lp.alive && node == kSentinel)); t_phase = __builtin_amdgcn_s_memrealtime(); }
         bool segment_done = false, started_shadow = false;
         f3 emission = mk(0.0f);
         if (lp.alive && node == kSentinel) {
@@ -406,7 +406,7 @@ k_render_pw(const RenderArgs A)
                 }
             }
         }
-        n_shadow += (unsigned long long)__popcll(__ballot(started_shadow));
+        n_shadow += (unsigned long long)popc(vote(started_shadow));
         bool end = false, finished = false;
         if (segment_done) {                                           // raygen :761-778
             lp.result += pd.radiance * att;
@@ -423,12 +423,12 @@ k_render_pw(const RenderArgs A)
                 if (lp.samples_left == 0u) { write_pixel(A, lp); lp.alive = false; finished = true; }
             }
         }
-        n_paths += (unsigned long long)__popcll(__ballot(end));
-        n_pixels += (unsigned long long)__popcll(__ballot(finished));
+        n_paths += (unsigned long long)popc(vote(end));
+        n_pixels += (unsigned long long)popc(vote(finished));
 
         refill_lanes<STATS>(A, q, lane, below, lp);
         if (STATS && t_drain == 0ull && q.shards_left == 0u && q.res_count == 0u) t_drain = __builtin_amdgcn_s_memrealtime();
-        if (__ballot(lp.alive) == 0ull) { if (q.shards_left == 0u && q.res_count == 0u) break; else continue; }
+        if (vote(lp.alive) == 0ull) { if (q.shards_left == 0u && q.res_count == 0u) break; else continue; }
 
         bool start_radiance = segment_done && !end;
         if (lp.alive && lp.new_path) {                                // camera path start, :727-745
@@ -455,21 +455,22 @@ k_render_pw(const RenderArgs A)
             rtmin = 0.01f; rtmax = 1e16f; best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu;
             node = root; sp = 0; cur_list = 0u; shadow_ray = false;
         }
-        n_radiance += (unsigned long long)__popcll(__ballot(start_radiance));
+        n_radiance += (unsigned long long)popc(vote(start_radiance));
 
         if (STATS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); t_in_shade += now - t_phase; t_phase = now; }
         // =========================== traversal: until SHADE_K lanes are parked =====================
+        const unsigned long long alive_mask = vote(lp.alive);          // fixed while the wave traverses
         for (;;) {
             const bool act = node != kSentinel;
-            const unsigned long long am = __ballot(act);
+            const unsigned long long am = vote(act);
             if (am == 0ull) break;
-            if (__popcll(__ballot(!act && lp.alive)) >= SHADE_K) break;
-            if (STATS) { n_steps += 1; n_lane_steps += (unsigned long long)__popcll(am); }
+            if (popc(alive_mask & ~am) >= SHADE_K) break;              // parked lanes: scalar arithmetic on the two masks
+            if (STATS) { n_steps += 1; n_lane_steps += (unsigned long long)popc(am); }
             if (NODE_FMT == 3) {
                 const bool at_inner = act && node >= 0;
                 const bool leaf_lane = node < 0;
-                const unsigned long long lmask = __ballot(leaf_lane);
-                const bool leaf_round = lmask != 0ull && (LEAF_K <= 1 || __popcll(lmask) >= LEAF_K || __ballot(at_inner) == 0ull);
+                const unsigned long long lmask = vote(leaf_lane);
+                const bool leaf_round = lmask != 0ull && (LEAF_K <= 1 || popc(lmask) >= LEAF_K || vote(at_inner) == 0ull);
                 bool next = false;
                 if (at_inner) {
                     uint32_t base;
@@ -525,8 +526,9 @@ k_render_pw(const RenderArgs A)
                     f1 = fminf(fminf(fmaxf(u0, u1), fmaxf(v0, v1)), fmaxf(w0, w1)) * kFarWiden;
                 } else if (NODE_FMT == 0) {
                     // fp32 nodes, slab planes as one full-rate fma each: t = p * (1/d) + (-o/d); lbvh_build.hip's pad_abs
-                    // covers the single rounding of -o/d
-                    const BvhNode* np = sc.nodes + node;
+                    // covers the single rounding of -o/d.  32-bit byte offset (scalar base + vector offset addressing; the
+                    // scene size limit in pt_set_scene keeps it below 4 GB)
+                    const BvhNode* np = (const BvhNode*)((const char*)sc.nodes + (size_t)((uint32_t)node << 6));
                     const float4 a = np->a, b = np->b, c = np->c;
                     const int4 ch = np->d;
                     c0 = ch.x; c1 = ch.y;
@@ -624,11 +626,11 @@ k_render_pw(const RenderArgs A)
                 }
             }
             const bool at_leaf = node < 0;       // kSentinel is positive
-            const unsigned long long lm = __ballot(at_leaf);
-            if (lm != 0ull && (LEAF_K <= 1 || __popcll(lm) >= LEAF_K || __ballot(node >= 0 && node != kSentinel) == 0ull)) {
+            const unsigned long long lm = vote(at_leaf);
+            if (lm != 0ull && (LEAF_K <= 1 || popc(lm) >= LEAF_K || vote(node >= 0 && node != kSentinel) == 0ull)) {
                 if (at_leaf) {
                     const int slot = ~node;
-                    const TriRecord* tp = sc.tris + slot;
+                    const TriRecord* tp = (const TriRecord*)((const char*)sc.tris + (size_t)((uint32_t)slot * 48u));
                     const float4 r0 = tp->r0, r1 = tp->r1, r2 = tp->r2;
                     float t;
                     const bool ok = tri_test_lazy(ro, rd, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), rtmin, rtmax, t);
@@ -755,9 +757,9 @@ k_trace_stream(const DeviceScene sc, uint32_t stack_entries, const float4* __res
     for (;;) {
         // retire finished rays, fetch new ones
         const bool idle_lane = node == kSentinel;
-        unsigned long long idle = __ballot(idle_lane);
+        unsigned long long idle = vote(idle_lane);
         const unsigned long long busy = ~idle;
-        if (idle != 0ull && (__popcll(idle) >= FETCH_K || busy == 0ull)) {
+        if (idle != 0ull && (popc(idle) >= FETCH_K || busy == 0ull)) {
             if (idle_lane && rid != 0xFFFFFFFFu) {
                 if (any_ray) { t_out[rid] = any_hit ? 1.0f : 0.0f; prim_out[rid] = any_hit ? 1u : 0u; }
                 else { t_out[rid] = best_slot >= 0 ? best_t : -1.0f; prim_out[rid] = best_prim; }
@@ -774,9 +776,9 @@ k_trace_stream(const DeviceScene sc, uint32_t stack_entries, const float4* __res
                     if (res_count < 256u) drained = true;
                     if (res_count == 0u) break;
                 }
-                const uint32_t want = (uint32_t)__popcll(idle);
+                const uint32_t want = (uint32_t)popc(idle);
                 const uint32_t take = want < res_count ? want : res_count;
-                const uint32_t rank = (uint32_t)__popcll(idle & below);
+                const uint32_t rank = (uint32_t)popc(idle & below);
                 if (idle_lane && rid == 0xFFFFFFFFu && rank < take) {
                     rid = res_first + rank;
                     const float4 a = rays[2ull * rid], b = rays[2ull * rid + 1];
@@ -788,15 +790,15 @@ k_trace_stream(const DeviceScene sc, uint32_t stack_entries, const float4* __res
                     node = sc.n_tris ? 0 : kSentinel; sp = 0;
                 }
                 res_first += take; res_count -= take;
-                idle = __ballot(rid == 0xFFFFFFFFu);
+                idle = vote(rid == 0xFFFFFFFFu);
             }
-            if (__ballot(node != kSentinel) == 0ull) {
-                if (__ballot(rid != 0xFFFFFFFFu) == 0ull && drained && res_count == 0u) break;   // nothing in flight, nothing left
+            if (vote(node != kSentinel) == 0ull) {
+                if (vote(rid != 0xFFFFFFFFu) == 0ull && drained && res_count == 0u) break;   // nothing in flight, nothing left
                 continue;       // rays of an empty scene retire on the next turn
             }
         }
         // one traversal step
-        { const unsigned long long vm = __ballot(node >= 0 && node != kSentinel); n_iter++; n_visit += (unsigned long long)__popcll(vm); n_vround += vm ? 1u : 0u; }
+        { const unsigned long long vm = vote(node >= 0 && node != kSentinel); n_iter++; n_visit += (unsigned long long)popc(vm); n_vround += vm ? 1u : 0u; }
         if (node >= 0 && node != kSentinel) {
             const BvhNode* np = sc.nodes + node;
             const float4 a = np->a, b = np->b, c = np->c;
@@ -832,9 +834,9 @@ k_trace_stream(const DeviceScene sc, uint32_t stack_entries, const float4* __res
             else { node = sp ? tos : kSentinel; sp = sp ? sp - 1 : 0; tos = st.pop(sp); }
         }
         const bool at_leaf = node < 0;
-        const unsigned long long lm = __ballot(at_leaf);
-        if (lm != 0ull && (__popcll(lm) >= LEAF_K || __ballot(node >= 0 && node != kSentinel) == 0ull)) {
-            n_tri += (unsigned long long)__popcll(lm); n_lround++;
+        const unsigned long long lm = vote(at_leaf);
+        if (lm != 0ull && (popc(lm) >= LEAF_K || vote(node >= 0 && node != kSentinel) == 0ull)) {
+            n_tri += (unsigned long long)popc(lm); n_lround++;
             if (at_leaf) {
                 const int slot = ~node;
                 const TriRecord* tp = sc.tris + slot;
@@ -886,9 +888,9 @@ k_trace_stream_w4(const DeviceScene sc, uint32_t stack_entries, const float4* __
     unsigned long long n_iter = 0, n_visit = 0, n_tri = 0, n_vround = 0, n_lround = 0;
     for (;;) {
         const bool idle_lane = node == kSentinel;
-        unsigned long long idle = __ballot(idle_lane);
+        unsigned long long idle = vote(idle_lane);
         const unsigned long long busy = ~idle;
-        if (idle != 0ull && (__popcll(idle) >= FETCH_K || busy == 0ull)) {
+        if (idle != 0ull && (popc(idle) >= FETCH_K || busy == 0ull)) {
             if (idle_lane && rid != 0xFFFFFFFFu) {
                 if (any_ray) { t_out[rid] = any_hit ? 1.0f : 0.0f; prim_out[rid] = any_hit ? 1u : 0u; }
                 else { t_out[rid] = best_slot >= 0 ? best_t : -1.0f; prim_out[rid] = best_prim; }
@@ -905,9 +907,9 @@ k_trace_stream_w4(const DeviceScene sc, uint32_t stack_entries, const float4* __
                     if (res_count < 256u) drained = true;
                     if (res_count == 0u) break;
                 }
-                const uint32_t want = (uint32_t)__popcll(idle);
+                const uint32_t want = (uint32_t)popc(idle);
                 const uint32_t take = want < res_count ? want : res_count;
-                const uint32_t rank = (uint32_t)__popcll(idle & below);
+                const uint32_t rank = (uint32_t)popc(idle & below);
                 if (idle_lane && rid == 0xFFFFFFFFu && rank < take) {
                     rid = res_first + rank;
                     const float4 a = rays[2ull * rid], b = rays[2ull * rid + 1];
@@ -918,19 +920,19 @@ k_trace_stream_w4(const DeviceScene sc, uint32_t stack_entries, const float4* __
                     node = sc.n_tris ? 0 : kSentinel; sp = 0; cur_list = 0;
                 }
                 res_first += take; res_count -= take;
-                idle = __ballot(rid == 0xFFFFFFFFu);
+                idle = vote(rid == 0xFFFFFFFFu);
             }
-            if (__ballot(node != kSentinel) == 0ull) {
-                if (__ballot(rid != 0xFFFFFFFFu) == 0ull && drained && res_count == 0u) break;
+            if (vote(node != kSentinel) == 0ull) {
+                if (vote(rid != 0xFFFFFFFFu) == 0ull && drained && res_count == 0u) break;
                 continue;
             }
         }
         const bool at_leaf = node < 0;
         const bool at_inner = node >= 0 && node != kSentinel;
-        const unsigned long long lm = __ballot(at_leaf);
-        const bool leaf_round = lm != 0ull && (__popcll(lm) >= LEAF_K || __ballot(at_inner) == 0ull);
-        { const unsigned long long vm = __ballot(at_inner); n_iter++; n_visit += (unsigned long long)__popcll(vm); n_vround += vm ? 1u : 0u;
-          if (leaf_round) { n_tri += (unsigned long long)__popcll(lm); n_lround++; } }
+        const unsigned long long lm = vote(at_leaf);
+        const bool leaf_round = lm != 0ull && (popc(lm) >= LEAF_K || vote(at_inner) == 0ull);
+        { const unsigned long long vm = vote(at_inner); n_iter++; n_visit += (unsigned long long)popc(vm); n_vround += vm ? 1u : 0u;
+          if (leaf_round) { n_tri += (unsigned long long)popc(lm); n_lround++; } }
         bool next = false;
         if (at_inner) {
             uint32_t base;
