@@ -155,11 +155,17 @@ __device__ __forceinline__ bool tri_test_lazy(const f3& o, const f3& d, const f3
     float U = dot_fma(s, p);
     f3 q = cross_fma(s, e1);
     float V = dot_fma(d, q);
-    if (det < 0.0f) { det = -det; U = -U; V = -V; p = -p; q = -q; }   // flipping q flips T below
+    // if (det < 0) negate det, U, V, T: as sign-bit arithmetic, without a branch (negating T afterwards gives the bits
+    // of the dot product with q negated: rounding is symmetric).  For det = -0.0 this flips where the comparison would
+    // not, but a zero determinant is rejected either way.
+    const uint32_t sgn = __float_as_uint(det) & 0x80000000u;
+    det = __uint_as_float(__float_as_uint(det) ^ sgn);
+    U = __uint_as_float(__float_as_uint(U) ^ sgn);
+    V = __uint_as_float(__float_as_uint(V) ^ sgn);
     bool ok = (det > 0.0f) && !(U < 0.0f || V < 0.0f || U + V > det);
     t_out = 0.0f;
     if (ok) {
-        const float T = dot_fma(e2, q);
+        const float T = __uint_as_float(__float_as_uint(dot_fma(e2, q)) ^ sgn);
         const float t = T / det;
         ok = (t > tmin && t < tmax);
         t_out = t;

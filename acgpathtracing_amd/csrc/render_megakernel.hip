@@ -363,7 +363,8 @@ k_render_pw(const RenderArgs A)
     f3 att = mk(1.0f);
     // ray in flight (rinv / gro: reciprocal direction and origin, in grid space for quantised nodes)
     f3 ro = mk(0.0f), rd = mk(0.0f, 0.0f, 1.0f), rinv = mk(1.0f), gro = mk(0.0f);
-    float rtmin = 0.0f, rtmax = 0.0f, best_t = 0.0f;
+    constexpr float rtmin = 0.01f;      // both ray kinds start at 0.01 (:750-757 and :660-672): a literal, not a register
+    float rtmax = 0.0f, best_t = 0.0f;
     int best_slot = -1; uint32_t best_prim = 0xFFFFFFFFu;
     int node = kSentinel, sp = 0, tos = kSentinel;
     uint32_t cur_base = 0, cur_list = 0;              // NODE_FMT 3: innermost group of pending children
@@ -399,7 +400,7 @@ k_render_pw(const RenderArgs A)
                         rinv = mk(G.cx * rinv.x, G.cy * rinv.y, G.cz * rinv.z);
                         if (NODE_FMT == 4) gro = mk(-(gro.x * rinv.x), -(gro.y * rinv.y), -(gro.z * rinv.z));   // t = q * rinv + gro
                     }
-                    rtmin = 0.01f; rtmax = Ldist - 0.01f; best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu;
+                    rtmax = Ldist - 0.01f; best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu;
                     node = root; sp = 0; cur_list = 0u; shadow_ray = true; shadow_hit = false; started_shadow = true;
                 } else {
                     segment_done = true;
@@ -452,7 +453,7 @@ k_render_pw(const RenderArgs A)
                 rinv = mk(G.cx * rinv.x, G.cy * rinv.y, G.cz * rinv.z);
                 if (NODE_FMT == 4) gro = mk(-(gro.x * rinv.x), -(gro.y * rinv.y), -(gro.z * rinv.z));
             }
-            rtmin = 0.01f; rtmax = 1e16f; best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu;
+            rtmax = 1e16f; best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu;
             node = root; sp = 0; cur_list = 0u; shadow_ray = false;
         }
         n_radiance += (unsigned long long)popc(vote(start_radiance));
