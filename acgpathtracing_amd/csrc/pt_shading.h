@@ -39,7 +39,9 @@ __device__ __forceinline__ f3 sample_ggx(float u1, float u2, float roughness, co
     const float phi = 2.0f * kPIf * u1;
     const float cosTheta = sqrtf((1.0f - u2) / (1.0f + (roughness * roughness - 1.0f) * u2));
     const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
-    const f3 H = mk(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta);
+    float sp, cp;
+    sincosf(phi, &sp, &cp);                  // the values of sinf(phi), cosf(phi) with one argument reduction (see shade_hit)
+    const f3 H = mk(sinTheta * cp, sinTheta * sp, cosTheta);
     // :470 compares in double against 0.999; 0.999f rounds up, so the float test is identical
     const f3 up = fabsf(N.z) < 0.999f ? mk(0.0f, 0.0f, 1.0f) : mk(1.0f, 0.0f, 0.0f);
     const f3 tangent = normalize(cross(up, N));
@@ -163,11 +165,19 @@ __device__ __forceinline__ bool shade_hit(const DeviceScene& sc, const ShadeCons
             } else {
             const float theta = acosf(sqrtf(z1));
             const float phi = 2.0f * kPIf * z2;
-            w_in = mk(sinf(theta) * cosf(phi), sinf(theta) * sinf(phi), cosf(theta));
+            // sincosf shares one argument reduction between the sine and the cosine of an angle; OCML's sinf / cosf
+            // are that same reduction + kernel with one output selected, so the values are the ones sinf(x) and cosf(x)
+            // return (checked bit for bit over the argument ranges: pt_selftest op 11, test_gpu_golden.py)
+            float st, ct, sp, cp;
+            sincosf(theta, &st, &ct);
+            sincosf(phi, &sp, &cp);
+            w_in = mk(st * cp, st * sp, ct);
             }
         } else {                                                                 // :368-380
             const float phi = 2.0f * kPIf * z2;
-            w_in = mk(cosf(phi) * sqrtf(1 - z1 * z1), sinf(phi) * sqrtf(1 - z1 * z1), z1);
+            float sp, cp;
+            sincosf(phi, &sp, &cp);
+            w_in = mk(cp * sqrtf(1 - z1 * z1), sp * sqrtf(1 - z1 * z1), z1);
         }
         onb_transform(N, w_in);
         pd.nxt_dir = w_in;

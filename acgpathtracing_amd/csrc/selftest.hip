@@ -48,6 +48,13 @@ __global__ void k_selftest(int op, const uint32_t* __restrict__ in, uint32_t n, 
         fout[4 * i] = o.x; fout[4 * i + 1] = o.y; fout[4 * i + 2] = o.z; out[4 * i + 3] = ok ? 1u : 0u;
         return;
     }
+    if (op == 11) {                                  // in: x; out: sinf(x), cosf(x), and the pair sincosf(x) returns
+        const float x = fin[i];
+        float sv, cv;
+        sincosf(x, &sv, &cv);
+        fout[4 * i] = sinf(x); fout[4 * i + 1] = cosf(x); fout[4 * i + 2] = sv; fout[4 * i + 3] = cv;
+        return;
+    }
     if (op == 10) {                                  // in: world, width, rank, sample; out: x, y
         const int* r = (const int*)in + 4 * i;
         int x, y;

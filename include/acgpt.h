@@ -228,7 +228,8 @@ int pt_bench_traversal(pt_ctx* ctx, const float* rays, size_t n, int repeats, in
  *   op 2  make_color (cuda/helpers.h:35-62)       in float[n][3]                  out uchar4[n]
  *   op 3..8 normalize, reflect, faceforward, lerp, cross, a / s (sutil/vec_math.h)  in float[n][10] = a, b, c, s   out float[n][3]
  *   op 9  refract (cuda/helpers.h:107-137)        in float[n][7] = i, n, ior      out float[n][4] = r, ok (uint32)
- *   op 10 StaticWorkDistribution::getSamplePixel (sutil/WorkDistribution.h:59-81)  in int32[n][4] = world, width, rank, sample   out int32[n][2] */
+ *   op 10 StaticWorkDistribution::getSamplePixel (sutil/WorkDistribution.h:59-81)  in int32[n][4] = world, width, rank, sample   out int32[n][2]
+ *   op 11 sinf(x), cosf(x) and the pair sincosf(x) gives (the samplers use the latter)   in float[n]   out float[n][4] */
 int pt_selftest(pt_ctx* ctx, int op, const void* in, size_t n, void* out);
 /* Diagnostic: after a launch of a "+ scheduler stats" kernel variant, three 100 MHz stamps per wave (start,
  * first time it found the work queue empty, end; 0 = wave did not run), HOST output of 3 * max_waves values. */

@@ -87,3 +87,22 @@ def test_gpu_work_distribution_exact(ctx):
             q = np.zeros((ns, 4), np.int32); q[:, 0] = world; q[:, 1] = w; q[:, 2] = r; q[:, 3] = np.arange(ns)
             got = run(ctx, 10, q, ns, np.zeros((ns, 2), np.int32))
             assert np.array_equal(got, m[r].astype(np.int32)), (world, w, h, r)
+
+
+def test_gpu_sincos_equals_sin_and_cos(ctx):
+    """The samplers take sin and cos of an angle from one sincosf call (one argument reduction instead of two).  That is
+    only admissible if the pair is, bit for bit, what sinf(x) and cosf(x) return: checked over the ranges the samplers
+    use (theta in [0, pi/2], phi in [0, 2 pi)), a general range, and special values."""
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([
+        np.linspace(0.0, 2.0 * np.pi, 4_000_001, dtype=np.float64).astype(np.float32),
+        (rng.random(4_000_000) * (2.0 * np.pi)).astype(np.float32),
+        np.arccos(np.sqrt(rng.random(4_000_000))).astype(np.float32),
+        (rng.standard_normal(2_000_000) * 1e3).astype(np.float32),
+        (rng.standard_normal(1_000_000) * 1e7).astype(np.float32),
+        np.array([0.0, -0.0, 1e-30, -1e-30, 1e-45, np.pi, np.pi / 2, 2 * np.pi, 3.4e38, -3.4e38, np.inf, -np.inf, np.nan], np.float32)])
+    out = run(ctx, 11, xs, xs.shape[0], np.zeros((xs.shape[0], 4), np.float32))
+    assert same_bits_or_both_nan(out[:, 2], out[:, 0]), "sincosf's sine differs from sinf"
+    assert same_bits_or_both_nan(out[:, 3], out[:, 1]), "sincosf's cosine differs from cosf"
+    fin = np.isfinite(xs)
+    assert np.allclose(out[fin & (np.abs(xs) < 1e4), 0], np.sin(xs[fin & (np.abs(xs) < 1e4)].astype(np.float64)), atol=2e-7)

@@ -581,10 +581,21 @@ def test_lifetime_and_streams():
     memory; launches enqueued on a caller-provided stream (torch's) are ordered with the caller's work."""
     import torch
     L = _native.hip()
-    torch.cuda.init()
-    free0, _ = torch.cuda.mem_get_info()
+    for attempt in range(3):          # torch's own device discovery failed once on a box where HIP itself was fine
+        try:
+            torch.cuda.init()
+            break
+        except RuntimeError:
+            if attempt == 2:
+                raise
+            import time
+            time.sleep(2.0)
     obj = pt.TinyObjWrapper(SCENE_FULL)
-    for it in range(6):
+    free0 = None
+    for it in range(7):
+        if it == 1:          # round 0 pays the runtime's one-time allocations (code objects, queues); measure from here
+            torch.cuda.synchronize(); torch.cuda.empty_cache()
+            free0, _ = torch.cuda.mem_get_info()
         state = pt.PathTracerState()
         pt.createDeviceContext(state, 0)
         for _ in range(3):
@@ -611,7 +622,9 @@ def test_lifetime_and_streams():
         del acc, fb
     torch.cuda.synchronize(); torch.cuda.empty_cache()
     free1, _ = torch.cuda.mem_get_info()
-    assert free0 - free1 < 64 << 20, "device memory leaked: %d MiB" % ((free0 - free1) >> 20)@pytest.mark.gpu
+    assert free0 - free1 < 64 << 20, "device memory leaked: %d MiB" % ((free0 - free1) >> 20)
+
+
 def test_ray_stream_kernel_bit_exact(full):
     """pt_bench_traversal (persistent ray-stream kernel, closest and any-hit rays mixed in one launch,
     more rays than resident lanes so the in-loop refill runs) against brute force."""
