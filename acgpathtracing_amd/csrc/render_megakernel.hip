@@ -323,7 +323,8 @@ k_render(const RenderArgs A)
 // DIAG (timing experiments only, never a product variant): 1 = 12 extra dependent VALU per inner
 // step, 2 = two extra 16-byte loads per inner step.
 // INNER: 0 = stack entirely in LDS, nested branches; 1 = stack top cached in a register (the LDS read of
-// a pop is consumed one push/pop later, off the critical path) and child selection by selects.
+// a pop is consumed one push/pop later, off the critical path) and child selection by selects; 2, 3 = the same with
+// that many node visits per trip through the loop control.
 template <int SHADE_K, int LEAF_K, int NODE_FMT, int THREADS, int MINW, bool STATS, int DIAG = 0, int INNER = 0>
 __global__ void __launch_bounds__(THREADS, MINW)
 k_render_pw(const RenderArgs A)
@@ -508,7 +509,11 @@ k_render_pw(const RenderArgs A)
                 }
                 continue;
             }
-            if (act && node >= 0) {
+            // INNER == 2: two node visits per trip through the loop control (a lane that reaches a leaf or runs dry in the
+            // first sits out the second)
+#pragma unroll
+            for (int visit = 0; visit < (INNER >= 2 ? INNER : 1); visit++)
+            if ((uint32_t)node < (uint32_t)kSentinel) {
                 float n0, f0, n1, f1; int c0, c1;
                 if (NODE_FMT == 5) {        // the two-step slab test (p - o) * (1/d): comparison variant
                     const BvhNode* np = sc.nodes + node;
@@ -1007,8 +1012,8 @@ struct VariantDesc { RenderKernel k; int threads; int node_fmt; const char* name
 // <SHADE_K, LEAF_K, NODE_FMT, THREADS>.
 static const VariantDesc kVariants[] = {
     {k_render, 256, 0, "sync fp32-nodes"},
-    {k_render_pw<48, 12, 0, 256, 4, false, 0, 1>, 256, 0, "pw K48 L12 fp32 w4, register stack top (default)"},
-    {k_render_pw<48, 12, 0, 256, 4, true, 0, 1>, 256, 0, "default + scheduler stats"},
+    {k_render_pw<44, 12, 0, 256, 4, false, 0, 2>, 256, 0, "pw K44 L12 fp32 w4, register stack top, two visits per loop trip (default)"},
+    {k_render_pw<44, 12, 0, 256, 4, true, 0, 2>, 256, 0, "default + scheduler stats"},
     {k_render_pw<40, 8, 0, 256, 4, false, 0, 1>, 256, 0, "pw K40 L8 fp32 w4, register stack top"},
     {k_render_pw<48, 8, 0, 256, 4, false>, 256, 0, "pw K48 L8 fp32 w4, LDS-only stack"},
     {k_render_pw<48, 8, 0, 256, 5, false, 0, 1>, 256, 0, "pw K48 L8 fp32 w5 (register-capped, spills)"},
@@ -1022,9 +1027,12 @@ static const VariantDesc kVariants[] = {
     {k_render_pw<48, 16, 3, 256, 4, false, 0, 1>, 256, 3, "pw K48 L16 four-wide"},
     {k_render_pw<40, 8, 3, 256, 4, false, 0, 1>, 256, 3, "pw K40 L8 four-wide"},
     {k_render_pw<48, 8, 3, 256, 5, false, 0, 1>, 256, 3, "pw K48 L8 four-wide w5"},
-    {k_render_pw<48, 8, 0, 256, 4, false, 0, 1>, 256, 0, "pw K48 L8 fp32 w4 (kLargeSceneVariant: chosen automatically above 100 k triangles)"},
+    {k_render_pw<48, 8, 0, 256, 4, false, 0, 2>, 256, 0, "pw K48 L8 fp32 w4, two visits per loop trip (kLargeSceneVariant: chosen automatically above 100 k triangles)"},
     {k_render_pw<48, 16, 0, 256, 4, false, 0, 1>, 256, 0, "pw K48 L16 fp32 w4"},
     {k_render_pw<44, 12, 0, 256, 4, false, 0, 1>, 256, 0, "pw K44 L12 fp32 w4"},
+    {k_render_pw<48, 12, 0, 256, 4, false, 0, 1>, 256, 0, "pw K48 L12 fp32 w4, one visit per loop trip (default until the two-visit loop)"},
+    {k_render_pw<48, 12, 0, 256, 4, false, 0, 3>, 256, 0, "pw K48 L12 fp32 w4, three visits per loop trip"},
+    {k_render_pw<40, 12, 0, 256, 4, false, 0, 2>, 256, 0, "pw K40 L12 fp32 w4, two visits per loop trip"},
     {k_render_pw<48, 12, 4, 256, 4, false, 0, 1>, 256, 4, "pw K48 L12 q16 nodes, fma decode w4"},
     {k_render_pw<48, 12, 5, 256, 4, false, 0, 1>, 256, 0, "pw K48 L12 fp32 w4, two-step slab test (p - o) * (1/d) (default until the fma form)"},
     {k_render_pw<48, 12, 1, 256, 4, false, 0, 1>, 256, 1, "pw K48 L12 q16 nodes w4"},
