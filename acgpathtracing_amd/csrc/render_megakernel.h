@@ -7,7 +7,7 @@ namespace ptd {
 
 constexpr int kRenderThreads = 256;   // 4 waves per workgroup (segment-synchronous variant)
 constexpr uint32_t kMaxTimedWaves = 16384;   // stats variants stamp start / queue-empty / end per wave behind the 8 counters
-constexpr int kDefaultVariant = 1;    // persistent traversal, K44 L12, two visits per loop trip, fp32 nodes, 4 waves/SIMD (no spills)
+constexpr int kDefaultVariant = 1;    // persistent traversal, K44 L16, two visits and two triangle tests per loop trip, fp32 nodes, 4 waves/SIMD (no spills)
 constexpr int kLargeSceneVariant = 16;   // the same with triangle rounds at 8 lanes: 3 % faster once the tree outgrows the caches
 constexpr uint32_t kLargeSceneTris = 100000;
 

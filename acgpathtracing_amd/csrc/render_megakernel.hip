@@ -325,7 +325,7 @@ k_render(const RenderArgs A)
 // INNER: 0 = stack entirely in LDS, nested branches; 1 = stack top cached in a register (the LDS read of
 // a pop is consumed one push/pop later, off the critical path) and child selection by selects; 2, 3 = the same with
 // that many node visits per trip through the loop control.
-template <int SHADE_K, int LEAF_K, int NODE_FMT, int THREADS, int MINW, bool STATS, int DIAG = 0, int INNER = 0>
+template <int SHADE_K, int LEAF_K, int NODE_FMT, int THREADS, int MINW, bool STATS, int DIAG = 0, int INNER = 0, int LEAVES = 1>
 __global__ void __launch_bounds__(THREADS, MINW)
 k_render_pw(const RenderArgs A)
 {
@@ -634,7 +634,9 @@ k_render_pw(const RenderArgs A)
             const bool at_leaf = node < 0;       // kSentinel is positive
             const unsigned long long lm = vote(at_leaf);
             if (lm != 0ull && (LEAF_K <= 1 || popc(lm) >= LEAF_K || vote(node >= 0 && node != kSentinel) == 0ull)) {
-                if (at_leaf) {
+#pragma unroll
+                for (int leaf = 0; leaf < LEAVES; leaf++)          // LEAVES == 2: a lane whose next node is a leaf again tests it in the same round
+                if (node < 0) {
                     const int slot = ~node;
                     const TriRecord* tp = (const TriRecord*)((const char*)sc.tris + (size_t)((uint32_t)slot * 48u));
                     const float4 r0 = tp->r0, r1 = tp->r1, r2 = tp->r2;
@@ -1012,8 +1014,8 @@ struct VariantDesc { RenderKernel k; int threads; int node_fmt; const char* name
 // <SHADE_K, LEAF_K, NODE_FMT, THREADS>.
 static const VariantDesc kVariants[] = {
     {k_render, 256, 0, "sync fp32-nodes"},
-    {k_render_pw<44, 12, 0, 256, 4, false, 0, 2>, 256, 0, "pw K44 L12 fp32 w4, register stack top, two visits per loop trip (default)"},
-    {k_render_pw<44, 12, 0, 256, 4, true, 0, 2>, 256, 0, "default + scheduler stats"},
+    {k_render_pw<44, 16, 0, 256, 4, false, 0, 2, 2>, 256, 0, "pw K44 L16 fp32 w4, register stack top, two visits and two triangle tests per loop trip (default)"},
+    {k_render_pw<44, 16, 0, 256, 4, true, 0, 2, 2>, 256, 0, "default + scheduler stats"},
     {k_render_pw<40, 8, 0, 256, 4, false, 0, 1>, 256, 0, "pw K40 L8 fp32 w4, register stack top"},
     {k_render_pw<48, 8, 0, 256, 4, false>, 256, 0, "pw K48 L8 fp32 w4, LDS-only stack"},
     {k_render_pw<48, 8, 0, 256, 5, false, 0, 1>, 256, 0, "pw K48 L8 fp32 w5 (register-capped, spills)"},
@@ -1033,6 +1035,11 @@ static const VariantDesc kVariants[] = {
     {k_render_pw<48, 12, 0, 256, 4, false, 0, 1>, 256, 0, "pw K48 L12 fp32 w4, one visit per loop trip (default until the two-visit loop)"},
     {k_render_pw<48, 12, 0, 256, 4, false, 0, 3>, 256, 0, "pw K48 L12 fp32 w4, three visits per loop trip"},
     {k_render_pw<40, 12, 0, 256, 4, false, 0, 2>, 256, 0, "pw K40 L12 fp32 w4, two visits per loop trip"},
+    {k_render_pw<44, 12, 0, 256, 4, false, 0, 2, 2>, 256, 0, "pw K44 L12 fp32 w4, two visits and two triangle tests per loop trip"},
+    {k_render_pw<44, 12, 0, 256, 4, false, 0, 2>, 256, 0, "pw K44 L12 fp32 w4, two visits, one triangle test per loop trip (default until the two-test round)"},
+    {k_render_pw<48, 8, 0, 256, 4, false, 0, 2, 2>, 256, 0, "pw K48 L8 V2 T2"},
+    {k_render_pw<48, 12, 0, 256, 4, false, 0, 2, 2>, 256, 0, "pw K48 L12 V2 T2"},
+    {k_render_pw<44, 16, 0, 256, 4, false, 0, 2, 3>, 256, 0, "pw K44 L16 V2 T3"},
     {k_render_pw<48, 12, 4, 256, 4, false, 0, 1>, 256, 4, "pw K48 L12 q16 nodes, fma decode w4"},
     {k_render_pw<48, 12, 5, 256, 4, false, 0, 1>, 256, 0, "pw K48 L12 fp32 w4, two-step slab test (p - o) * (1/d) (default until the fma form)"},
     {k_render_pw<48, 12, 1, 256, 4, false, 0, 1>, 256, 1, "pw K48 L12 q16 nodes w4"},
