@@ -11,6 +11,7 @@ namespace ptd {
 struct LbvhResult {
     BvhNode*   nodes = nullptr;        // device, n_nodes (fp32 boxes, 64 B)
     QNode*     qnodes = nullptr;       // device, n_nodes (16-bit grid boxes, 32 B)
+    BvhNode*   cnodes = nullptr;       // device, n_nodes (centre + half-extent boxes, 64 B)
     QGrid      grid = {};              // world -> grid transform of qnodes
     TriRecord* tris = nullptr;         // device, n_tris, Morton order
     uint4*     wrecs = nullptr;        // device, n_wrecs x 48 B: four-wide nodes + triangles (wide_bvh.hip)

@@ -428,6 +428,33 @@ __global__ void k_ploc_merge(const Cluster* __restrict__ cin, const uint32_t* __
 }
 
 
+// --- 7. centre / half-extent copy of the nodes ------------------------------------------------------
+// Slab planes from a centre c and a half extent h need no per-axis min / max (half-rate instructions):
+// near = (c - o)/d - h/|d|, far = (c - o)/d + h/|d|.  h is inflated by 1e-6 so that [c - h, c + h] contains the
+// fp32 [lo, hi] it came from whatever way c and h rounded.  Same slots as BvhNode: lo -> c, hi -> h.
+__device__ __forceinline__ void centre_half(float lo, float hi, float& c, float& h)
+{
+    if (!(lo <= hi)) { c = 0.0f; h = -1.0f; return; }       // empty child (single-triangle scene): never hit
+    c = 0.5f * lo + 0.5f * hi;
+    h = fmaxf(c - lo, hi - c) * 1.000001f + 1e-30f;
+}
+__global__ void k_centre_nodes(const BvhNode* __restrict__ nodes, uint32_t n, BvhNode* __restrict__ cn)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const BvhNode nd = nodes[i];
+    BvhNode o;
+    // child 0: lo (a.x a.y a.z) hi (a.w b.x b.y); child 1: lo (b.z b.w c.x) hi (c.y c.z c.w)
+    centre_half(nd.a.x, nd.a.w, o.a.x, o.a.w);
+    centre_half(nd.a.y, nd.b.x, o.a.y, o.b.x);
+    centre_half(nd.a.z, nd.b.y, o.a.z, o.b.y);
+    centre_half(nd.b.z, nd.c.y, o.b.z, o.c.y);
+    centre_half(nd.b.w, nd.c.z, o.b.w, o.c.z);
+    centre_half(nd.c.x, nd.c.w, o.c.x, o.c.w);
+    o.d = nd.d;
+    cn[i] = o;
+}
+
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); return false; } } while (0)
 
 namespace {
@@ -454,6 +481,7 @@ void free_lbvh(LbvhResult& r)
 {
     if (r.nodes) (void)hipFree(r.nodes);
     if (r.qnodes) (void)hipFree(r.qnodes);
+    if (r.cnodes) (void)hipFree(r.cnodes);
     if (r.tris) (void)hipFree(r.tris);
     if (r.wrecs) (void)hipFree(r.wrecs);
     if (r.keys_sorted) (void)hipFree(r.keys_sorted);
@@ -498,6 +526,7 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
     HIPCK(sc.alloc(&d_lparent, (size_t)n * 4));
     HIPCK(hipMalloc((void**)&out.nodes, (size_t)n_nodes * sizeof(BvhNode)));
     HIPCK(hipMalloc((void**)&out.qnodes, (size_t)n_nodes * sizeof(QNode)));
+    HIPCK(hipMalloc((void**)&out.cnodes, (size_t)n_nodes * sizeof(BvhNode)));
     HIPCK(hipMalloc((void**)&out.tris, (size_t)n * sizeof(TriRecord)));
     HIPCK(hipMalloc((void**)&out.keys_sorted, (size_t)n * 4));
     HIPCK(hipMalloc((void**)&out.vals_sorted, (size_t)n * 4));
@@ -567,6 +596,7 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
     } else {
         k_single_node<<<1, 1, 0, stream>>>(d_tlo, d_thi, out.nodes, d_nhi, out.qnodes, d_bounds);
     }
+    k_centre_nodes<<<(n_nodes + 255) / 256, 256, 0, stream>>>(out.nodes, n_nodes, out.cnodes);
     HIPCK(hipGetLastError());
     HIPCK(hipEventRecord(sc.ev1, stream));
     HIPCK(hipMemcpyAsync(h_bounds, d_bounds, 24, hipMemcpyDeviceToHost, stream));

@@ -54,6 +54,7 @@ struct QGrid {
 struct DeviceScene {
     const BvhNode*     nodes;
     const QNode*       qnodes;
+    const BvhNode*     cnodes;    // the same tree with every child box as centre + half extent (layout of BvhNode: lo -> centre, hi -> half extent)
     QGrid              grid;
     const TriRecord*   tris;
     const uint4*       wrecs;     // four-wide tree: 48-byte records, wide nodes and triangles in one array (wide_bvh.hip)

@@ -394,8 +394,8 @@ k_render_pw(const RenderArgs A)
                 lp.result += emission;                                // :760 (before the radiance term)
                 if (want_shadow) {
                     ro = P; rd = L;
-                    rinv = NODE_FMT == 0 ? mk(finite_rcp(L.x), finite_rcp(L.y), finite_rcp(L.z)) : mk(fast_rcp(L.x), fast_rcp(L.y), fast_rcp(L.z));
-                    if (NODE_FMT == 0) gro = mk(-(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z));
+                    rinv = (NODE_FMT == 0 || NODE_FMT == 6) ? mk(finite_rcp(L.x), finite_rcp(L.y), finite_rcp(L.z)) : mk(fast_rcp(L.x), fast_rcp(L.y), fast_rcp(L.z));
+                    if (NODE_FMT == 0 || NODE_FMT == 6) gro = mk(-(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z));
                     if (NODE_FMT == 1 || NODE_FMT == 2 || NODE_FMT == 4) {
                         gro = mk((ro.x - G.ox) * G.icx, (ro.y - G.oy) * G.icy, (ro.z - G.oz) * G.icz);
                         rinv = mk(G.cx * rinv.x, G.cy * rinv.y, G.cz * rinv.z);
@@ -447,8 +447,8 @@ k_render_pw(const RenderArgs A)
             start_radiance = true;
         }
         if (start_radiance) {                                         // traceRadiance :750-757
-            rinv = NODE_FMT == 0 ? mk(finite_rcp(rd.x), finite_rcp(rd.y), finite_rcp(rd.z)) : mk(fast_rcp(rd.x), fast_rcp(rd.y), fast_rcp(rd.z));
-            if (NODE_FMT == 0) gro = mk(-(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z));
+            rinv = (NODE_FMT == 0 || NODE_FMT == 6) ? mk(finite_rcp(rd.x), finite_rcp(rd.y), finite_rcp(rd.z)) : mk(fast_rcp(rd.x), fast_rcp(rd.y), fast_rcp(rd.z));
+            if (NODE_FMT == 0 || NODE_FMT == 6) gro = mk(-(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z));
             if (NODE_FMT == 1 || NODE_FMT == 2 || NODE_FMT == 4) {
                 gro = mk((ro.x - G.ox) * G.icx, (ro.y - G.oy) * G.icy, (ro.z - G.oz) * G.icz);
                 rinv = mk(G.cx * rinv.x, G.cy * rinv.y, G.cz * rinv.z);
@@ -548,6 +548,24 @@ k_render_pw(const RenderArgs A)
                     const float w0 = __builtin_fmaf(c.x, rinv.z, gro.z), w1 = __builtin_fmaf(c.w, rinv.z, gro.z);
                     n1 = fmaxf(fmaxf(fminf(u0, u1), fminf(v0, v1)), fmaxf(fminf(w0, w1), rtmin));
                     f1 = fminf(fminf(fmaxf(u0, u1), fmaxf(v0, v1)), fmaxf(w0, w1)) * kFarWiden;
+                } else if (NODE_FMT == 6) {
+                    // centre / half-extent nodes: near = (c - o)/d - h/|d|, far = (c - o)/d + h/|d|: full-rate arithmetic only,
+                    // the |.| is a source modifier
+                    const BvhNode* np = (const BvhNode*)((const char*)sc.cnodes + (size_t)((uint32_t)node << 6));
+                    const float4 a = np->a, b = np->b, c = np->c;
+                    const int4 ch = np->d;
+                    c0 = ch.x; c1 = ch.y;
+                    const float ax = fabsf(rinv.x), ay = fabsf(rinv.y), az = fabsf(rinv.z);
+                    const float cx0 = __builtin_fmaf(a.x, rinv.x, gro.x), hx0 = a.w * ax;
+                    const float cy0 = __builtin_fmaf(a.y, rinv.y, gro.y), hy0 = b.x * ay;
+                    const float cz0 = __builtin_fmaf(a.z, rinv.z, gro.z), hz0 = b.y * az;
+                    n0 = fmaxf(fmaxf(cx0 - hx0, cy0 - hy0), fmaxf(cz0 - hz0, rtmin));
+                    f0 = fminf(fminf(cx0 + hx0, cy0 + hy0), cz0 + hz0) * kFarWiden;
+                    const float cx1 = __builtin_fmaf(b.z, rinv.x, gro.x), hx1 = c.y * ax;
+                    const float cy1 = __builtin_fmaf(b.w, rinv.y, gro.y), hy1 = c.z * ay;
+                    const float cz1 = __builtin_fmaf(c.x, rinv.z, gro.z), hz1 = c.w * az;
+                    n1 = fmaxf(fmaxf(cx1 - hx1, cy1 - hy1), fmaxf(cz1 - hz1, rtmin));
+                    f1 = fminf(fminf(cx1 + hx1, cy1 + hy1), cz1 + hz1) * kFarWiden;
                 } else if (NODE_FMT == 4) {
                     // 16-bit grid nodes, one conversion + one fma per plane (the grid's one-cell outward rounding covers the
                     // fma form's error, which is below 0.01 cell)
@@ -1040,6 +1058,9 @@ static const VariantDesc kVariants[] = {
     {k_render_pw<48, 8, 0, 256, 4, false, 0, 2, 2>, 256, 0, "pw K48 L8 V2 T2"},
     {k_render_pw<48, 12, 0, 256, 4, false, 0, 2, 2>, 256, 0, "pw K48 L12 V2 T2"},
     {k_render_pw<44, 16, 0, 256, 4, false, 0, 2, 3>, 256, 0, "pw K44 L16 V2 T3"},
+    {k_render_pw<44, 16, 6, 256, 4, false, 0, 2, 2>, 256, 0, "pw K44 L16 V2 T2 centre / half-extent nodes"},
+    {k_render_pw<44, 16, 4, 256, 4, false, 0, 2, 2>, 256, 4, "pw K44 L16 V2 T2 q16 nodes, fma decode"},
+    {k_render_pw<44, 16, 3, 256, 4, false, 0, 2, 2>, 256, 3, "pw K44 L16 T2 four-wide 8-bit nodes"},
     {k_render_pw<48, 12, 4, 256, 4, false, 0, 1>, 256, 4, "pw K48 L12 q16 nodes, fma decode w4"},
     {k_render_pw<48, 12, 5, 256, 4, false, 0, 1>, 256, 0, "pw K48 L12 fp32 w4, two-step slab test (p - o) * (1/d) (default until the fma form)"},
     {k_render_pw<48, 12, 1, 256, 4, false, 0, 1>, 256, 1, "pw K48 L12 q16 nodes w4"},
