@@ -3,6 +3,9 @@
 // pointer valid until unmap(), getHostPointer() the pixels on the host.  Modes: DEVICE (device
 // memory + explicit copy) and ZERO_COPY (pinned host memory mapped into the device); the two GL /
 // P2P modes of the reference have no meaning on a headless node.
+// Constructor as in the reference, (type, width, height): the buffer allocates in the *current* render
+// context, the way CUDAOutputBuffer allocates on the current CUDA device (sutil/CUDAOutputBuffer.h:58,
+// 100-137).  createDeviceContext() makes its context current; setContext() rebinds explicitly.
 #pragma once
 #include <cstdint>
 #include <vector>
@@ -12,19 +15,26 @@ namespace acgpt {
 
 enum class OutputBufferType { DEVICE = 0, ZERO_COPY = 2 };
 
+// the render context OutputBuffer allocates in unless told otherwise (one per process, like the current device)
+inline pt_ctx*& currentContext() { static pt_ctx* ctx = nullptr; return ctx; }
+inline void makeContextCurrent(pt_ctx* ctx) { currentContext() = ctx; }
+
 template <typename PIXEL_FORMAT>
 class OutputBuffer {
 public:
-    OutputBuffer(pt_ctx* ctx, OutputBufferType type, int32_t width, int32_t height) : m_ctx(ctx), m_type(type) { resize(width, height); }
+    OutputBuffer(OutputBufferType type, int32_t width, int32_t height) : m_ctx(currentContext()), m_type(type) { resize(width, height); }
     ~OutputBuffer() { release(); }
     OutputBuffer(const OutputBuffer&) = delete;
     OutputBuffer& operator=(const OutputBuffer&) = delete;
 
     void setDevice(int32_t) {}
+    // move the buffer to another render context (re-allocates; contents are not carried over)
+    void setContext(pt_ctx* ctx) { release(); m_ctx = ctx; resize(m_width, m_height); }
     void setStream(void* stream) { PT_CHECK(m_ctx, pt_set_stream(m_ctx, stream)); }
 
     void resize(int32_t width, int32_t height)
     {
+        if (!m_ctx) throw Exception("OutputBuffer: no render context is current (createDeviceContext / makeContextCurrent first)");
         release();
         m_width = width < 1 ? 1 : width;
         m_height = height < 1 ? 1 : height;

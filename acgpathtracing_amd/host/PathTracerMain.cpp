@@ -81,6 +81,9 @@ static void allocAccumulation(PathTracerState& state)
     void* p = nullptr;
     PT_CHECK(state.context, pt_device_malloc(state.context, &p, (size_t)state.params.width * state.params.height * 4 * sizeof(float)));
     state.params.accumulationBuffer = (float*)p;
+    // zero-filled: with pt_set_partition(rank, world) the pixels of other ranks are never written and the
+    // cross-rank reduce(SUM) relies on them being 0 (the reference's single-GPU cudaMalloc leaves them undefined)
+    PT_CHECK(state.context, pt_device_memset(state.context, p, 0, (size_t)state.params.width * state.params.height * 4 * sizeof(float)));
 }
 
 static void initializeTheLaunch(PathTracerState& state)                   // :143-164
@@ -130,6 +133,7 @@ static void initCamera()                                                 // :228
 static void createDeviceContext(PathTracerState& state)                  // :240-258
 {
     if (pt_create(&state.context, state.device) != 0) throw Exception(std::string("createDeviceContext: ") + pt_last_error(nullptr));
+    makeContextCurrent(state.context);      // OutputBuffer(type, w, h) allocates here, as CUDAOutputBuffer does on the current device
 }
 
 static void buildTheAccelarationStructure(PathTracerState& state, const TinyObjWrapper& objs)   // :260-398 (+ :544-627)
@@ -219,7 +223,7 @@ int main(int argc, char** argv)
         std::cout << "Launch Initialized" << std::endl;
         uint64_t rays = 0;
         {
-            OutputBuffer<uchar4> output_buffer(state.context, zero_copy ? OutputBufferType::ZERO_COPY : OutputBufferType::DEVICE,
+            OutputBuffer<uchar4> output_buffer(zero_copy ? OutputBufferType::ZERO_COPY : OutputBufferType::DEVICE,
                                                state.params.width, state.params.height);
             size_t next_key = 0;
             for (int f = 0; f < frames;) {

@@ -1,87 +1,102 @@
-// Trackball.cpp — behaviour of sutil/Trackball.cpp:51-137 (latitude/longitude orbit with
-// 0.5 degree per pixel, latitude clamped to +-89 degrees, zoom factor 1.1).
+// Trackball.cpp — see Trackball.h for the behaviour this implements.  The arithmetic (degree <-> radian
+// round trips in fp32, the libm calls and their argument types) is what
+// tests/test_host_golden.py::test_trackball_matches_reference holds bit for bit against the reference's
+// sutil/Trackball.cpp:51-137 compiled in the authoring container.
 #include "Trackball.h"
 #include <algorithm>
 #include <cmath>
-#include <utility>
 
 namespace acgpt {
 
-static inline float to_radians(float deg) { return deg * kPIf / 180.0f; }
-static inline float to_degrees(float rad) { return rad * k1_PIf * 180.0f; }
+namespace {
+constexpr float kDegPerPixel = 0.5f;
+constexpr float kLatLimitDeg = 89.0f;
+
+inline float as_degrees(float rad) { return rad * k1_PIf * 180.0f; }
+inline float as_radians(float deg) { return deg * kPIf / 180.0f; }
+inline float clamp_lat(float deg) { return std::min(kLatLimitDeg, std::max(-kLatLimitDeg, deg)); }
+}  // namespace
 
 void Trackball::startTracking(int x, int y)
 {
-    m_prevPosX = x;
-    m_prevPosY = y;
-    m_performTracking = true;
+    pointer_.x = x;
+    pointer_.y = y;
+    pointer_.dragging = true;
 }
 
-void Trackball::updateTracking(int x, int y, int, int)
+void Trackball::updateTracking(int x, int y, int /*canvasWidth*/, int /*canvasHeight*/)
 {
-    if (!m_performTracking) { startTracking(x, y); return; }
-    const int dx = x - m_prevPosX, dy = y - m_prevPosY;
-    m_prevPosX = x;
-    m_prevPosY = y;
-    m_latitude = to_radians(std::min(89.0f, std::max(-89.0f, to_degrees(m_latitude) + 0.5f * dy)));
-    m_longitude = to_radians(fmod(to_degrees(m_longitude) - 0.5f * dx, 360.0f));
-    updateCamera();
-    if (!m_gimbalLock) {
+    if (!pointer_.dragging) {       // first event of a drag only anchors the pointer
+        startTracking(x, y);
+        return;
+    }
+    const int moved_x = x - pointer_.x;
+    const int moved_y = y - pointer_.y;
+    pointer_.x = x;
+    pointer_.y = y;
+
+    pos_.lat = as_radians(clamp_lat(as_degrees(pos_.lat) + kDegPerPixel * moved_y));
+    pos_.lon = as_radians(fmod(as_degrees(pos_.lon) - kDegPerPixel * moved_x, 360.0f));
+    placeCamera();
+
+    if (!frame_locked_) {           // free exploration: the orbit frame follows the camera
         reinitOrientationFromCamera();
-        m_camera->setUp(m_w);
+        cam_->setUp(axes_[kPole]);
     }
 }
 
-void Trackball::updateCamera()
+float3 Trackball::offsetOnSphere() const
 {
-    float3 local;
-    local.x = cos(m_latitude) * sin(m_longitude);
-    local.y = cos(m_latitude) * cos(m_longitude);
-    local.z = sin(m_latitude);
-    const float3 dirWS = m_u * local.x + m_v * local.y + m_w * local.z;
-    if (m_viewMode == EyeFixed) {
-        const float3& eye = m_camera->eye();
-        m_camera->setLookat(eye - dirWS * m_cameraEyeLookatDistance);
-    } else {
-        const float3& lookat = m_camera->lookat();
-        m_camera->setEye(lookat + dirWS * m_cameraEyeLookatDistance);
-    }
+    const float on_right   = cos(pos_.lat) * sin(pos_.lon);
+    const float on_forward = cos(pos_.lat) * cos(pos_.lon);
+    const float on_pole    = sin(pos_.lat);
+    return axes_[kRight] * on_right + axes_[kForward] * on_forward + axes_[kPole] * on_pole;
+}
+
+void Trackball::placeCamera()
+{
+    const float3 offset = offsetOnSphere();
+    if (mode_ == LookAtFixed) cam_->setEye(cam_->lookat() + offset * radius_);
+    else                      cam_->setLookat(cam_->eye() - offset * radius_);
 }
 
 void Trackball::setReferenceFrame(const float3& u, const float3& v, const float3& w)
 {
-    m_u = u; m_v = v; m_w = w;
-    const float3 dirWS = -normalize(m_camera->lookat() - m_camera->eye());
-    const float lx = dot(dirWS, u), ly = dot(dirWS, v), lz = dot(dirWS, w);
-    m_longitude = atan2(lx, ly);
-    m_latitude = asin(lz);
+    axes_[kRight] = u;
+    axes_[kForward] = v;
+    axes_[kPole] = w;
+    // where the eye sits on the sphere of the new frame
+    const float3 towards_eye = -normalize(cam_->lookat() - cam_->eye());
+    const float cr = dot(towards_eye, u), cf = dot(towards_eye, v), cp = dot(towards_eye, w);
+    pos_.lon = atan2(cr, cf);
+    pos_.lat = asin(cp);
 }
 
 void Trackball::zoom(int direction)
 {
-    const float z = (direction > 0) ? 1 / m_zoomMultiplier : m_zoomMultiplier;
-    m_cameraEyeLookatDistance *= z;
-    const float3& lookat = m_camera->lookat();
-    const float3& eye = m_camera->eye();
-    m_camera->setEye(lookat + (eye - lookat) * z);
-}
-
-void Trackball::reinitOrientationFromCamera()
-{
-    m_camera->UVWFrame(m_u, m_v, m_w);
-    m_u = normalize(m_u);
-    m_v = normalize(m_v);
-    m_w = normalize(-m_w);
-    std::swap(m_v, m_w);
-    m_latitude = 0.0f;
-    m_longitude = 0.0f;
-    m_cameraEyeLookatDistance = length(m_camera->lookat() - m_camera->eye());
+    const float scale = direction > 0 ? 1 / wheel_factor_ : wheel_factor_;
+    radius_ *= scale;
+    const float3 pivot = cam_->lookat();
+    cam_->setEye(pivot + (cam_->eye() - pivot) * scale);
 }
 
 bool Trackball::wheelEvent(int dir)
 {
     zoom(dir);
     return true;
+}
+
+void Trackball::reinitOrientationFromCamera()
+{
+    // camera frame U (right), V (up), W (view direction) -> orbit frame {right, towards the eye, up}:
+    // the camera's up becomes the pole and the sphere position restarts at the origin of the new frame
+    float3 cam_u, cam_v, cam_w;
+    cam_->UVWFrame(cam_u, cam_v, cam_w);
+    axes_[kRight] = normalize(cam_u);
+    axes_[kForward] = normalize(-cam_w);
+    axes_[kPole] = normalize(cam_v);
+    pos_ = SpherePos();
+    radius_ = length(cam_->lookat() - cam_->eye());
 }
 
 }  // namespace acgpt

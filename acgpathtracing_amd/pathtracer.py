@@ -277,6 +277,9 @@ def _alloc_accumulation(state):
     nbytes = int(state.params.width) * int(state.params.height) * 16
     p = C.c_void_p()
     _check(state.context, L.pt_device_malloc(state.context, C.byref(p), nbytes), "accumulation alloc")
+    # zero-filled: under pt_set_partition(rank, world) the pixels of other ranks are never written and the
+    # cross-rank reduce(SUM) of distributed.reduce_accumulation relies on them being 0
+    _check(state.context, L.pt_device_memset(state.context, p, 0, nbytes), "accumulation clear")
     state.params.accumulationBuffer = p.value
     state._accum_bytes = nbytes
 
