@@ -45,7 +45,7 @@ class PathTraceParams(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("radiance_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("paths", C.c_uint64),
-                ("kernel_ms", C.c_float), ("launch_ms", C.c_float), ("pixels", C.c_uint32), ("grid_blocks", C.c_uint32), ("sample_chunks", C.c_uint32), ("reserved", C.c_uint32),
+                ("kernel_ms", C.c_float), ("launch_ms", C.c_float), ("pixels", C.c_uint32), ("grid_blocks", C.c_uint32), ("sample_chunks", C.c_uint32), ("variant", C.c_uint32),
                 ("trav_wave_steps", C.c_uint64), ("trav_lane_steps", C.c_uint64),
                 ("shade_wave_rounds", C.c_uint64), ("shade_lane_rounds", C.c_uint64)]
 

@@ -33,6 +33,32 @@ __device__ __forceinline__ void onb_transform(const f3& n, f3& p)
     const f3 tg = cross(bn, n);
     p = p.x * tg + p.y * bn + p.z * n;
 }
+// cosine_sample_hemisphere :341-353.  sincosf shares one argument reduction between the sine and the cosine of an
+// angle; OCML's sinf / cosf are that same reduction + kernel with one output selected, so the values are the ones
+// sinf(x) and cosf(x) return (checked bit for bit over the argument ranges: pt_selftest op 11, test_gpu_golden.py)
+__device__ __forceinline__ f3 cosine_sample_hemisphere(float eta1, float eta2)
+{
+    const float theta = acosf(sqrtf(eta1));
+    const float phi = 2.0f * kPIf * eta2;
+    float st, ct, sp, cp;
+    sincosf(theta, &st, &ct);
+    sincosf(phi, &sp, &cp);
+    return mk(st * cp, st * sp, ct);
+}
+// the same sampler with v_sin_f32 / v_cos_f32 and sqrt(1 - z1) for sin(acos(sqrt(z1))): kernel variant 10 only
+__device__ __forceinline__ f3 cosine_sample_hemisphere_fast(float eta1, float eta2)
+{
+    const float ct = sqrtf(eta1), stt = sqrtf(1.0f - eta1);
+    return mk(stt * __builtin_amdgcn_cosf(eta2), stt * __builtin_amdgcn_sinf(eta2), ct);
+}
+// uniform_sample_hemisphere :368-380 (the theta computed at :372 is unused there)
+__device__ __forceinline__ f3 uniform_sample_hemisphere(float u1, float u2)
+{
+    const float phi = 2.0f * kPIf * u2;
+    float sp, cp;
+    sincosf(phi, &sp, &cp);
+    return mk(cp * sqrtf(1 - u1 * u1), sp * sqrtf(1 - u1 * u1), u1);
+}
 // sampleGGX :455-476 (roughness is the literal 0.2 of :880)
 __device__ __forceinline__ f3 sample_ggx(float u1, float u2, float roughness, const f3& N)
 {
@@ -158,27 +184,8 @@ __device__ __forceinline__ bool shade_hit(const DeviceScene& sc, const ShadeCons
         const float z1 = rnd(s);
         const float z2 = rnd(s);
         f3 w_in;
-        if (K.useIS) {                                                           // :341-353
-            if (TRIG_DIAG) {
-                const float ct = sqrtf(z1), stt = sqrtf(1.0f - z1);
-                w_in = mk(stt * __builtin_amdgcn_cosf(z2), stt * __builtin_amdgcn_sinf(z2), ct);
-            } else {
-            const float theta = acosf(sqrtf(z1));
-            const float phi = 2.0f * kPIf * z2;
-            // sincosf shares one argument reduction between the sine and the cosine of an angle; OCML's sinf / cosf
-            // are that same reduction + kernel with one output selected, so the values are the ones sinf(x) and cosf(x)
-            // return (checked bit for bit over the argument ranges: pt_selftest op 11, test_gpu_golden.py)
-            float st, ct, sp, cp;
-            sincosf(theta, &st, &ct);
-            sincosf(phi, &sp, &cp);
-            w_in = mk(st * cp, st * sp, ct);
-            }
-        } else {                                                                 // :368-380
-            const float phi = 2.0f * kPIf * z2;
-            float sp, cp;
-            sincosf(phi, &sp, &cp);
-            w_in = mk(cp * sqrtf(1 - z1 * z1), sp * sqrtf(1 - z1 * z1), z1);
-        }
+        if (K.useIS) w_in = TRIG_DIAG ? cosine_sample_hemisphere_fast(z1, z2) : cosine_sample_hemisphere(z1, z2);
+        else         w_in = uniform_sample_hemisphere(z1, z2);
         onb_transform(N, w_in);
         pd.nxt_dir = w_in;
         pd.nxt_org = P;

@@ -55,6 +55,22 @@ __global__ void k_selftest(int op, const uint32_t* __restrict__ in, uint32_t n, 
         fout[4 * i] = sinf(x); fout[4 * i + 1] = cosf(x); fout[4 * i + 2] = sv; fout[4 * i + 3] = cv;
         return;
     }
+    if (op >= 12 && op <= 18) {                      // pathTracerPrograms.cu helpers (see acgpt.h for the record layouts)
+        const int in_w = (op == 12 || op == 16) ? 6 : op == 13 ? 4 : op == 17 ? 7 : op == 18 ? 3 : 2;
+        const float* r = fin + in_w * i;
+        f3 o = mk(0.0f);
+        switch (op) {
+            case 12: o = mk(r[3], r[4], r[5]); onb_transform(mk(r[0], r[1], r[2]), o); break;
+            case 13: o = mk(safe_div(r[0], r[3]), safe_div(r[1], r[3]), safe_div(r[2], r[3])); break;
+            case 14: o = cosine_sample_hemisphere(r[0], r[1]); break;
+            case 15: o = uniform_sample_hemisphere(r[0], r[1]); break;
+            case 16: o = sample_ggx(r[0], r[1], r[2], mk(r[3], r[4], r[5])); break;
+            case 17: o = fresnel_conductor(r[0], mk(r[1], r[2], r[3]), mk(r[4], r[5], r[6])); break;
+            default: fout[i] = fr_dielectric(r[0], r[1], r[2]); return;
+        }
+        fout[3 * i] = o.x; fout[3 * i + 1] = o.y; fout[3 * i + 2] = o.z;
+        return;
+    }
     if (op == 10) {                                  // in: world, width, rank, sample; out: x, y
         const int* r = (const int*)in + 4 * i;
         int x, y;

@@ -19,10 +19,20 @@ tiles (sutil/WorkDistribution.h) of the same steps, then ONE RCCL reduce of the 
 accumulation buffer to rank 0 + make_color there, all inside the timed region.  Per-GPU work
 shrinks with N -> "scaling": "strong".
 
-One JSON line on rank 0.  `roofline` prices the megakernel against HBM (SURVEY.md §8d:
-B_ray = 64*ceil(log2 T) + 64 bytes per ray + 36*W*H per launch); `cpu_baseline` times the CPU
-oracle (oracle/, scalar C++ restatement, std::thread over the host cores) on a bounded sample of
-the same workload — reported, not the target.
+One JSON line on rank 0.
+
+`roofline` prices the megakernel against the resource that can bind it.  The kernel is BVH pointer
+chasing + fp32 shading: no matrix work, so MFMA never applies.  HBM applies only when the scene
+(nodes + triangle records) exceeds the 256 MB Infinity Cache; a scene that fits the 32 MB of L2 (every
+Cornell-class input: 140 KB) or the Infinity Cache is served on chip, and the SURVEY.md §8d byte model
+(B_ray = 64*ceil(log2 T) + 64 bytes per ray + 36*W*H per step) then describes cache traffic, not HBM —
+it is reported as `hbm_model` and never as `frac`.  For those scenes `bound` is "valu": achieved =
+algorithmic fp32 flops (F_ray = 48*ceil(log2 T) + 168 per ray) over the kernel's
+HIP-event time, peak = 157.3 TFLOP/s fp32 vector.  `traffic` = measured HBM bytes per kernel launch and
+`measured` = the unit-busy fractions, both from the committed PMC summary of this config's default
+command (profiles/, separate --pmc passes, gfx950 FETCH_SIZE correction), whatever --steps is.
+`cpu_baseline` times the CPU oracle (oracle/, scalar C++ restatement, std::thread over the host cores)
+on a bounded sample of the same workload — reported, not the target.
 """
 import argparse
 import ctypes as C
@@ -42,7 +52,9 @@ WIDTH, HEIGHT = 1920, 1080
 SPP_PER_LAUNCH = 128
 MAX_DEPTH = 8
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP32_PEAK_TFLOPS = 157.3
+FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32 vector (non-matrix) peak
+L2_BYTES = 8 * 4 * 1024 * 1024       # 4 MB per XCD
+MALL_BYTES = 256 * 1024 * 1024       # Infinity Cache
 
 
 def parse():
@@ -63,7 +75,9 @@ def parse():
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--variant", type=int, default=-1, help="render kernel variant (-1 = library default)")
     ap.add_argument("--fuse", type=int, default=8, help="steps per kernel launch (pt_launch_frames); 1 = one launch per step")
+    ap.add_argument("--chunks", type=int, default=0, help="sample runs per pixel (pt_set_sample_chunks); 0 = automatic")
     ap.add_argument("--save", default="", help="write the final framebuffer as PPM (rank 0)")
+    ap.add_argument("--save-accum", default="", help="write the final float4 accumulation buffer as .npy (rank 0)")
     a = ap.parse_args()
     preset = {2: ("cornell_box_diffuse.obj", 8, 8), 3: ("cornell_box.obj", 32, 16), 5: ("stress_1m.obj", 2, 8)}[a.config]
     if a.scene is None:
@@ -121,6 +135,78 @@ def cpu_baseline(pt, obj, params, cpu_spp):
                       (os.path.basename(obj.path), q.width, q.height, q.maxDepth, cpu_spp, secs, rays)}, rays / max(1, q.width * q.height * cpu_spp)
 
 
+def primary_miss_fraction(p, info):
+    """Fraction of the pixels whose camera ray (through the pixel centre) misses the scene's bounding box: those
+    paths are one ray that fails at the root.  Part of the workload BASELINE config 2 defines (a 16:9 frame around a
+    square box), stated so that the Mray/s figure can be read with it."""
+    W, H = int(p.width), int(p.height)
+    xs = (np.arange(W, dtype=np.float64) + 0.5) / W * 2.0 - 1.0
+    ys = (np.arange(H, dtype=np.float64) + 0.5) / H * 2.0 - 1.0
+    f = lambda v: np.array([v.x, v.y, v.z], np.float64)
+    eye, U, V, Wv = f(p.cameraEye), f(p.cameraU), f(p.cameraV), f(p.cameraW)
+    d = xs[None, :, None] * U + ys[:, None, None] * V + Wv
+    lo = np.array(info.scene_lo, np.float64); hi = np.array(info.scene_hi, np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t0 = (lo - eye) / d; t1 = (hi - eye) / d
+    tn = np.nanmax(np.minimum(t0, t1), axis=-1); tf = np.nanmin(np.maximum(t0, t1), axis=-1)
+    return float(1.0 - ((tn <= tf) & (tf > 0)).mean())
+
+
+def pmc_summary(config):
+    """The committed PMC summary of this config's default bench command (tools/profile_bench.sh +
+    tools/summarize_prof.py): newest profiles/r*_c<config>_summary.json."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_c%d_summary.json" % config)))
+    if not files:
+        return None, None
+    try:
+        return json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
+def roofline_block(a, info, world, fuse, kernel_ms, rays_per_launch, steps_per_launch, variant_name):
+    T = max(2, info.n_tris)
+    levels = math.ceil(math.log2(T))
+    b_ray = 64 * levels + 64
+    f_ray = 48 * levels + 168
+    k_avg_ms = sum(kernel_ms) / max(1, len(kernel_ms))
+    ksec = k_avg_ms * 1e-3
+    my_pixels = a.width * a.height / world
+    algo_bytes = rays_per_launch * b_ray + 36.0 * my_pixels * steps_per_launch
+    algo_flops = rays_per_launch * f_ray
+    scene_bytes = int(info.node_bytes) + int(info.tri_bytes)
+    resident = "L2" if scene_bytes <= L2_BYTES else ("Infinity Cache" if scene_bytes <= MALL_BYTES else "HBM")
+    model_gbs = algo_bytes / ksec / 1e9 if ksec > 0 else 0.0
+    valu_tf = algo_flops / ksec / 1e12 if ksec > 0 else 0.0
+    summ, src = pmc_summary(a.config)
+    default_cmd = (a.scene == {2: "cornell_box_diffuse.obj", 3: "cornell_box.obj", 5: "stress_1m.obj"}[a.config]
+                   and (a.width, a.height, a.spp) == (WIDTH, HEIGHT, SPP_PER_LAUNCH) and world == 1 and a.variant < 0
+                   and not a.blocks_per_cu and a.fuse == 8 and a.chunks == 0)
+    traffic, measured = None, None
+    if summ and default_cmd:
+        der = summ.get("derived", {})
+        traffic = der.get("hbm_bytes_per_launch")
+        measured = {"source": src, "kernel": summ.get("kernel_stats", {}).get("name"),
+                    "kernel_ms_avg_rocprof": summ.get("kernel_stats", {}).get("avg_ms"),
+                    "steps_per_launch_profiled": summ.get("steps_per_kernel_launch", 8),
+                    "ta_busy": der.get("ta_busy_frac(256 TAs)"),
+                    "valu_issue_busy": der.get("valu_issue_busy_frac(2cyc/instr,1024 SIMDs)"),
+                    "lane_utilisation": der.get("valu_lane_utilisation"),
+                    "l2_hit": der.get("l2_hit_rate"), "l1_miss_per_access": der.get("l1_miss_per_access"),
+                    "hbm_GBps": (traffic / (summ["kernel_stats"]["avg_ms"] * 1e-3) / 1e9) if traffic and summ.get("kernel_stats") else None}
+    r = {"kernel": variant_name, "kernel_ms_avg": k_avg_ms, "scene_bytes": scene_bytes, "scene_resident_in": resident,
+         "traffic": traffic, "measured": measured,
+         "hbm_model": {"algorithmic_bytes_per_ray": b_ray, "algorithmic_bytes_per_launch": algo_bytes, "GBps": model_gbs,
+                       "note": "SURVEY.md 8d byte model; for a cache-resident scene these bytes are served by L1/L2/Infinity Cache, so this is not an HBM fraction"},
+         "valu_model": {"algorithmic_flops_per_ray": f_ray, "TFLOPs": valu_tf, "frac_of_fp32_vector_peak": valu_tf / FP32_PEAK_TFLOPS}}
+    if resident == "HBM":
+        r.update({"bound": "hbm", "achieved": model_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": model_gbs / HBM_PEAK_GBS})
+    else:
+        r.update({"bound": "valu", "achieved": valu_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": valu_tf / FP32_PEAK_TFLOPS})
+    return r
+
+
 def main():
     a = parse()
     import torch
@@ -161,6 +247,7 @@ def main():
     p.frameBuffer = fb.data_ptr() if world == 1 else None
     state.params = p
     assert L.pt_set_partition(state.context, rank, world) == 0
+    assert L.pt_set_sample_chunks(state.context, a.chunks) == 0
     assert L.pt_set_stream(state.context, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
     if a.blocks_per_cu or a.variant >= 0:
         assert L.pt_set_tuning(state.context, a.blocks_per_cu, max(a.variant, 0)) == 0
@@ -193,12 +280,14 @@ def main():
     t0 = time.perf_counter()
     rays = shadow = paths = 0
     kernel_ms = []
+    last_stats = None
     k = 0
     while k < a.steps:
         n = min(fuse, a.steps - k)
         s = launch(k, n)
         rays += int(s.radiance_rays); shadow += int(s.shadow_rays); paths += int(s.paths)
         kernel_ms.append(float(s.kernel_ms))
+        last_stats = s
         k += n
     if world > 1:
         if rehearse:
@@ -218,24 +307,11 @@ def main():
     # ---- report ---------------------------------------------------------------------------------------
     if rank == 0:
         all_rays = tot_rays + tot_shadow
-        T = max(2, info.n_tris)
-        b_ray = 64 * math.ceil(math.log2(T)) + 64
-        f_ray = 48 * math.ceil(math.log2(T)) + 168
-        k_avg_ms = sum(kernel_ms) / max(1, len(kernel_ms))
         n_launches = max(1, len(kernel_ms))
-        my_rays_per_launch = (rays + shadow) / n_launches
-        my_pixels = a.width * a.height / world
-        algo_bytes = my_rays_per_launch * b_ray + 36.0 * my_pixels * (a.steps / n_launches)
-        achieved = algo_bytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        default_workload = (a.config == 2 and a.scene == "cornell_box_diffuse.obj" and (a.width, a.height, a.spp, a.max_depth) == (WIDTH, HEIGHT, SPP_PER_LAUNCH, MAX_DEPTH)
-                            and world == 1 and a.variant < 0 and not a.blocks_per_cu and fuse == 8 and a.steps % 8 == 0)
-        if default_workload and os.path.exists(prof):     # PMC traffic was collected on exactly this workload
-            try:
-                traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        vname = L.pt_variant_name(int(last_stats.variant))
+        roof = roofline_block(a, info, world, fuse, kernel_ms, (rays + shadow) / n_launches, a.steps / n_launches,
+                              vname.decode() if vname else "?")
+        miss = primary_miss_fraction(p, info)
         out = {
             "metric": "Mray/s at 1080p, %d spp, %d bounces (radiance + shadow rays per second)" % (a.spp * a.steps, a.max_depth),
             "value": all_rays / elapsed / 1e6,
@@ -254,15 +330,17 @@ def main():
                        "steps_per_kernel_launch": fuse, "kernel_launches": n_launches,
                        "parallelism": "pixel tiles 8x4 over %d GPU(s)%s" % (world, ", RCCL reduce of float4 accumulation" if world > 1 else ""),
                        "rays": int(all_rays), "paths": int(tot_paths), "rays_per_path": all_rays / max(1.0, tot_paths),
+                       "primary_miss_fraction": miss, "rays_entering_scene": int(all_rays - miss * tot_paths),
+                       "Mray_per_s_entering_scene": (all_rays - miss * tot_paths) / elapsed / 1e6,
+                       "sample_runs_per_pixel": int(last_stats.sample_chunks),
                        "bvh": {"nodes": info.n_nodes, "max_depth": info.max_depth, "stack_entries": info.stack_entries, "build_ms": info.build_ms}},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_render", "kernel_ms_avg": k_avg_ms,
-                         "algorithmic_bytes_per_ray": b_ray, "algorithmic_bytes_per_launch": algo_bytes,
-                         "valu_frac_secondary": (my_rays_per_launch * f_ray / (k_avg_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS) if k_avg_ms > 0 else 0.0},
+            "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:
             base, _ = cpu_baseline(pt, obj, p, a.cpu_spp)
             out["cpu_baseline"] = base
+        if a.save_accum:
+            np.save(a.save_accum, accum.cpu().numpy())
         if a.save:
             img = fb.cpu().numpy()[::-1, :, :3]
             with open(a.save, "wb") as fh:

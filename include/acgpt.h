@@ -96,7 +96,7 @@ typedef struct pt_stats {
     uint32_t pixels;          /* pixels this launch rendered (tile partition) */
     uint32_t grid_blocks;     /* persistent workgroups launched                */
     uint32_t sample_chunks;   /* runs per pixel this launch used (pt_set_sample_chunks) */
-    uint32_t reserved;
+    uint32_t variant;         /* render kernel variant that ran (pt_variant_name)      */
     /* scheduler diagnostics (0 for the segment-synchronous variant):          */
     uint64_t trav_wave_steps;   /* BVH loop iterations summed over waves       */
     uint64_t trav_lane_steps;   /* ... times lanes with a ray in flight        */
@@ -229,7 +229,15 @@ int pt_bench_traversal(pt_ctx* ctx, const float* rays, size_t n, int repeats, in
  *   op 3..8 normalize, reflect, faceforward, lerp, cross, a / s (sutil/vec_math.h)  in float[n][10] = a, b, c, s   out float[n][3]
  *   op 9  refract (cuda/helpers.h:107-137)        in float[n][7] = i, n, ior      out float[n][4] = r, ok (uint32)
  *   op 10 StaticWorkDistribution::getSamplePixel (sutil/WorkDistribution.h:59-81)  in int32[n][4] = world, width, rank, sample   out int32[n][2]
- *   op 11 sinf(x), cosf(x) and the pair sincosf(x) gives (the samplers use the latter)   in float[n]   out float[n][4] */
+ *   op 11 sinf(x), cosf(x) and the pair sincosf(x) gives (the samplers use the latter)   in float[n]   out float[n][4]
+ * the OptiX-free helpers of pathTracerPrograms.cu, golden vectors from the reference's own text (oracle/_ref):
+ *   op 12 OrthonormalBasis(n).inverse_transform(p) (:54-85)        in float[n][6] = n, p            out float[n][3]
+ *   op 13 safeDivide(float3, float) (:265-284)                      in float[n][4] = a, b            out float[n][3]
+ *   op 14 cosine_sample_hemisphere (:341-353)                       in float[n][2] = eta1, eta2      out float[n][3]
+ *   op 15 uniform_sample_hemisphere (:368-380)                      in float[n][2] = u1, u2          out float[n][3]
+ *   op 16 sampleGGX (:455-476)                                      in float[n][6] = u1, u2, roughness, N   out float[n][3]
+ *   op 17 fresnelSchlickConductor (:494-510)                        in float[n][7] = cosTheta, eta, k       out float[n][3]
+ *   op 18 FrDielectric (:534-559)                                   in float[n][3] = cosThetaI, etaI, etaT  out float[n][1] */
 int pt_selftest(pt_ctx* ctx, int op, const void* in, size_t n, void* out);
 /* Diagnostic: after a launch of a "+ scheduler stats" kernel variant, three 100 MHz stamps per wave (start,
  * first time it found the work queue empty, end; 0 = wave did not run), HOST output of 3 * max_waves values. */

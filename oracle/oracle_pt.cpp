@@ -670,6 +670,53 @@ ORC_API void orc_vec_op(int op, const float* a, const float* b, const float* c, 
     out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
 
+/* ---- the OptiX-free helpers of pathTracerPrograms.cu, one export each, same signatures as ref_math_shim.cpp's
+ * exports over the reference's own text (tests/test_oracle_golden.py compares them bit for bit) ---- */
+ORC_API void orc_onb_transform(const float* n3, const float* p3, size_t n, float* out3)
+{
+    for (size_t i = 0; i < n; i++) {
+        OrthonormalBasis onb(mk(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]));
+        f3 p = mk(p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]);
+        onb.inverse_transform(p);
+        out3[3 * i] = p.x; out3[3 * i + 1] = p.y; out3[3 * i + 2] = p.z;
+    }
+}
+ORC_API void orc_safe_divide(const float* a, const float* b, size_t n, float* out)
+{
+    for (size_t i = 0; i < n; i++) out[i] = safeDivide(a[i], b[i]);
+}
+ORC_API void orc_safe_divide3(const float* a3, const float* b, size_t n, float* out3)
+{
+    for (size_t i = 0; i < n; i++) { f3 r = safeDivide(mk(a3[3 * i], a3[3 * i + 1], a3[3 * i + 2]), b[i]); out3[3 * i] = r.x; out3[3 * i + 1] = r.y; out3[3 * i + 2] = r.z; }
+}
+ORC_API void orc_sample_hemisphere(int which, const float* u1, const float* u2, size_t n, float* out3)
+{
+    for (size_t i = 0; i < n; i++) {
+        f3 p = mk(0.0f);
+        if (which == 0) cosine_sample_hemisphere(u1[i], u2[i], p);
+        else            uniform_sample_hemisphere(u1[i], u2[i], p);
+        out3[3 * i] = p.x; out3[3 * i + 1] = p.y; out3[3 * i + 2] = p.z;
+    }
+}
+ORC_API void orc_sample_ggx(const float* u1, const float* u2, const float* roughness, const float* n3, size_t n, float* out3)
+{
+    for (size_t i = 0; i < n; i++) {
+        f3 r = sampleGGX(u1[i], u2[i], roughness[i], mk(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2]));
+        out3[3 * i] = r.x; out3[3 * i + 1] = r.y; out3[3 * i + 2] = r.z;
+    }
+}
+ORC_API void orc_fresnel_conductor(const float* cos_theta, const float* eta3, const float* k3, size_t n, float* out3)
+{
+    for (size_t i = 0; i < n; i++) {
+        f3 r = fresnelSchlickConductor(cos_theta[i], mk(eta3[3 * i], eta3[3 * i + 1], eta3[3 * i + 2]), mk(k3[3 * i], k3[3 * i + 1], k3[3 * i + 2]));
+        out3[3 * i] = r.x; out3[3 * i + 1] = r.y; out3[3 * i + 2] = r.z;
+    }
+}
+ORC_API void orc_fr_dielectric(const float* cos_i, const float* eta_i, const float* eta_t, size_t n, float* out)
+{
+    for (size_t i = 0; i < n; i++) out[i] = FrDielectric(cos_i[i], eta_i[i], eta_t[i]);
+}
+
 /* Camera::UVWFrame, sutil/Camera.cpp:34-45 */
 ORC_API void orc_camera_uvw(const float* eye, const float* lookat, const float* up, float fovY, float aspect,
                             float* U3, float* V3, float* W3)
@@ -735,8 +782,27 @@ ORC_API void orc_trace_any(void* s, const float* rays, size_t n, int use_bvh, ui
  * ->frameBuffer are ignored).  rank/world select the WorkDistribution partition; chunks: see raygen_pixel
  * (1 = the reference's summation order).
  * stats_out: radiance_rays, shadow_rays, paths.  Returns wall seconds. */
+static double render_impl(void* s, const pt_params* params, float* accumulation, uint8_t* framebuffer,
+                          int use_bvh, int n_threads, int rank, int world, int chunks, const int* window, uint64_t* stats_out);
+
 ORC_API double orc_render(void* s, const pt_params* params, float* accumulation, uint8_t* framebuffer,
                           int use_bvh, int n_threads, int rank, int world, int chunks, uint64_t* stats_out)
+{
+    return render_impl(s, params, accumulation, framebuffer, use_bvh, n_threads, rank, world, chunks, NULL, stats_out);
+}
+
+/* The same launch restricted to the pixels of a window {x0, y0, width, height} of the full image: pixels outside are
+ * neither computed nor written (accumulation / framebuffer stay full-size arrays).  A pixel's value does not depend on
+ * any other pixel (:721 seeds by pixel index, :782-814 writes only image_index), so a window of a 1920x1080 launch can
+ * be checked without rendering the other two million pixels on the CPU. */
+ORC_API double orc_render_window(void* s, const pt_params* params, float* accumulation, uint8_t* framebuffer,
+                                 int use_bvh, int n_threads, int chunks, const int* window4, uint64_t* stats_out)
+{
+    return render_impl(s, params, accumulation, framebuffer, use_bvh, n_threads, 0, 1, chunks, window4, stats_out);
+}
+
+static double render_impl(void* s, const pt_params* params, float* accumulation, uint8_t* framebuffer,
+                          int use_bvh, int n_threads, int rank, int world, int chunks, const int* window, uint64_t* stats_out)
 {
     const Scene& sc = *(Scene*)s;
     const int w = params->width, h = params->height;
@@ -756,6 +822,7 @@ ORC_API double orc_render(void* s, const pt_params* params, float* accumulation,
             for (int si = b; si < e; si++) {
                 int px, py; sample_pixel(world, w, rank, si, px, py);
                 if (px >= w || py >= h) continue;
+                if (window && (px < window[0] || py < window[1] || px >= window[0] + window[2] || py >= window[1] + window[3])) continue;
                 raygen_pixel(sc, *params, use_bvh, chunks, (uint32_t)px, (uint32_t)py, accumulation, framebuffer, c);
             }
         }

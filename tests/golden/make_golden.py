@@ -4,7 +4,8 @@
 Runs only where /root/reference exists: it loads oracle/_ref/libref.so, which oracle/Makefile
 builds from the reference's host-compilable sources where they lie (cuda/random.h, cuda/helpers.h,
 sutil/vec_math.h, sutil/Camera.cpp, sutil/Trackball.cpp, sutil/WorkDistribution.h,
-PathTracer_Optix/TinyObjWrapper.cpp + util/tiny_obj_loader.h).  The outputs are DATA (inputs and
+PathTracer_Optix/TinyObjWrapper.cpp + util/tiny_obj_loader.h, and the OptiX-free sampling / BSDF helpers of
+PathTracer_Optix/pathTracerPrograms.cu that oracle/extract_ptprog_math.py lifts verbatim into oracle/_ref at build time).  The outputs are DATA (inputs and
 expected outputs); no reference source text is stored.  Deterministic: fixed numpy seeds.
 
     python tests/golden/make_golden.py
@@ -66,6 +67,50 @@ def main():
     out["refract_i"], out["refract_n"], out["refract_ior"] = I.astype(np.float32), N.astype(np.float32), iors
     out["refract_r"] = np.stack([r[0] for r in rr])
     out["refract_ok"] = np.array([r[1] for r in rr], np.uint8)
+
+    # ---- the OptiX-free helpers inside pathTracerPrograms.cu (:54-85, :265-284, :341-380, :455-476, :494-510, :534-559),
+    # run from the reference's own text (oracle/extract_ptprog_math.py -> oracle/_ref/ptprog_math.inc -> libref.so) ----
+    m = 3000
+    unit = lambda a: (a / np.linalg.norm(a, axis=1, keepdims=True)).astype(np.float32)
+    Nn = unit(rng.normal(size=(m, 3)))
+    # ONB branch edge |n.x| vs |n.z|, axis-aligned normals, and sampleGGX's |N.z| < 0.999 switch from both sides
+    Nn[:6] = np.array([[0, 1, 0], [0, -1, 0], [1, 0, 0], [0, 0, 1], [0, 0, -1], [-1, 0, 0]], np.float32)
+    Nn[6:10] = unit(np.array([[0.5, 0.3, 0.5], [0.5, 0.3, -0.5], [-0.5, 0.1, 0.5], [0.5000001, 0.2, 0.5]], np.float64))
+    for k, z in enumerate([0.999, 0.99900001, 0.9989999, 0.9990001, -0.999, -0.9990001, -0.9989999, 0.9995, 0.998]):
+        s_xy = np.sqrt(max(0.0, 1.0 - z * z))
+        Nn[10 + k] = np.array([s_xy * 0.6, s_xy * 0.8, z], np.float32)
+    Pp = rng.normal(size=(m, 3)).astype(np.float32)
+    out["math_onb_n"], out["math_onb_p"] = Nn, Pp
+    out["math_onb_out"] = R.onb_transform(Nn, Pp)
+    sa = (rng.normal(size=(m, 3)) * rng.choice([1e-3, 1.0, 1e4], size=(m, 1))).astype(np.float32)
+    sb = rng.normal(size=m).astype(np.float32)
+    sb[:40:4] = 0.0; sb[1:40:4] = -0.0; sb[2:40:4] = np.float32(1e-42); sb[3:12:4] = np.inf
+    out["math_sdiv_a"], out["math_sdiv_b"] = sa, sb
+    out["math_sdiv_out"] = R.safe_divide(sa[:, 0], sb)
+    out["math_sdiv3_out"] = R.safe_divide3(sa, sb)
+    # the samplers' inputs are rnd() outputs: k / 2^24, k in [0, 2^24)
+    u1 = (rng.integers(0, 1 << 24, size=m).astype(np.float32) / np.float32(1 << 24)).astype(np.float32)
+    u2 = (rng.integers(0, 1 << 24, size=m).astype(np.float32) / np.float32(1 << 24)).astype(np.float32)
+    edge = np.array([0.0, 1.0 / (1 << 24), 0.25, 0.5, 0.75, ((1 << 24) - 1) / float(1 << 24)], np.float32)
+    u1[:36] = np.repeat(edge, 6); u2[:36] = np.tile(edge, 6)
+    out["math_u1"], out["math_u2"] = u1, u2
+    out["math_cosine_out"] = R.sample_hemisphere(0, u1, u2)
+    out["math_uniform_out"] = R.sample_hemisphere(1, u1, u2)
+    rough = np.full(m, 0.2, np.float32); rough[m // 2:] = rng.choice([0.05, 0.5, 1.0], size=m - m // 2).astype(np.float32)
+    out["math_ggx_rough"] = rough
+    out["math_ggx_out"] = R.sample_ggx(u1, u2, rough, Nn)
+    ct = (rng.random(m) * 1.0).astype(np.float32); ct[:5] = [0.0, 1.0, 1e-4, 0.5, 0.9999999]
+    eta = np.tile(np.array([1.45, 0.7, 1.55], np.float32), (m, 1)); kk = np.tile(np.array([3.0, 2.2, 3.5], np.float32), (m, 1))
+    eta[m // 2:] = (rng.random((m - m // 2, 3)) * 3 + 0.1).astype(np.float32); kk[m // 2:] = (rng.random((m - m // 2, 3)) * 5).astype(np.float32)
+    out["math_fc_cos"], out["math_fc_eta"], out["math_fc_k"] = ct, eta, kk
+    out["math_fc_out"] = R.fresnel_conductor(ct, eta, kk)
+    ci = (rng.random(m) * 2.4 - 1.2).astype(np.float32)          # beyond [-1, 1]: the clamp at :535
+    ci[:8] = [0.0, -0.0, 1.0, -1.0, 1e-7, -1e-7, 0.3, -0.3]
+    ei = np.ones(m, np.float32); et = rng.choice([1.0, 1.33, 1.5, 2.4, 0.75], size=m).astype(np.float32)
+    ei[m // 2:] = rng.choice([1.0, 1.5, 2.4], size=m - m // 2).astype(np.float32)
+    out["math_fd_cos"], out["math_fd_etai"], out["math_fd_etat"] = ci, ei, et
+    out["math_fd_out"] = R.fr_dielectric(ci, ei, et)
+    assert (out["math_fd_out"] == 1.0).mean() > 0.02, "total internal reflection must be covered"
 
     # ---- Camera::UVWFrame (sutil/Camera.cpp) ---------------------------------------------------------------
     cams = [((278, 273, -900), (278, 273, 330), (0, 1, 0), 35.0, 1.0),

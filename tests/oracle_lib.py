@@ -5,6 +5,8 @@ import os
 
 import numpy as np
 
+from math_binding import MathMixin
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 
@@ -21,9 +23,12 @@ def _cpu_has_fma():
     return False
 
 
-class Oracle:
+class Oracle(MathMixin):
+    prefix = "orc_"
+
     def __init__(self, lib, path):
         self.lib, self.path = lib, path
+        self._bind_math()
         vp, sz = C.c_void_p, C.c_size_t
         L = lib
         L.orc_tea4.argtypes = [C.c_uint32, C.c_uint32]; L.orc_tea4.restype = C.c_uint32
@@ -39,6 +44,7 @@ class Oracle:
         L.orc_trace_closest.argtypes = [vp, vp, sz, C.c_int, vp, vp]; L.orc_trace_closest.restype = None
         L.orc_trace_any.argtypes = [vp, vp, sz, C.c_int, vp]; L.orc_trace_any.restype = None
         L.orc_render.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]; L.orc_render.restype = C.c_double
+        L.orc_render_window.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]; L.orc_render_window.restype = C.c_double
         L.orc_uses_hw_fma.argtypes = []; L.orc_uses_hw_fma.restype = C.c_int
 
     # -- small functions -------------------------------------------------------------
@@ -139,6 +145,21 @@ class OracleScene:
 
 
 _cached = None
+
+
+def render_window(scene, params, window, accumulation=None, use_bvh=True, threads=0, chunks=1):
+    """One launch on the CPU for the pixels of window = (x0, y0, w, h) only.  Returns (accumulation[H,W,4] with only the
+    window filled, stats dict, seconds); pass the returned accumulation back in for the next frame of a progressive run."""
+    h, w = int(params.height), int(params.width)
+    if accumulation is None:
+        accumulation = np.zeros((h, w, 4), np.float32)
+    win = np.array(window, np.int32)
+    stats = np.zeros(3, np.uint64)
+    if threads <= 0:
+        threads = os.cpu_count() or 1
+    secs = scene.orc.lib.orc_render_window(scene.h, C.byref(params), accumulation.ctypes.data, None, int(use_bvh), int(threads),
+                                           int(chunks), win.ctypes.data, stats.ctypes.data)
+    return accumulation, {"radiance_rays": int(stats[0]), "shadow_rays": int(stats[1]), "paths": int(stats[2])}, float(secs)
 
 
 def load(build_if_missing=True):

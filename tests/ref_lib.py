@@ -8,6 +8,8 @@ import os
 
 import numpy as np
 
+from math_binding import MathMixin
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PATH = os.path.join(ROOT, "oracle", "_ref", "libref.so")
 
@@ -16,9 +18,12 @@ def available():
     return os.path.exists(PATH)
 
 
-class Ref:
+class Ref(MathMixin):
+    prefix = "ref_"
+
     def __init__(self):
         L = self.lib = C.CDLL(PATH)
+        self._bind_math()
         vp, sz = C.c_void_p, C.c_size_t
         L.ref_tea4.argtypes = [C.c_uint32, C.c_uint32]; L.ref_tea4.restype = C.c_uint32
         L.ref_rnd_stream.argtypes = [C.c_uint32, sz, vp, vp]; L.ref_rnd_stream.restype = None

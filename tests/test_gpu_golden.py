@@ -106,3 +106,47 @@ def test_gpu_sincos_equals_sin_and_cos(ctx):
     assert same_bits_or_both_nan(out[:, 3], out[:, 1]), "sincosf's cosine differs from cosf"
     fin = np.isfinite(xs)
     assert np.allclose(out[fin & (np.abs(xs) < 1e4), 0], np.sin(xs[fin & (np.abs(xs) < 1e4)].astype(np.float64)), atol=2e-7)
+
+
+def ulp_distance(a, b):
+    """distance in units of the last place of the larger magnitude (0 for equal bits / both NaN)"""
+    a = np.ascontiguousarray(a, np.float32).astype(np.float64); b = np.ascontiguousarray(b, np.float32).astype(np.float64)
+    sp = np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32)).astype(np.float64)
+    d = np.abs(a - b) / sp
+    return np.where(np.isnan(a) & np.isnan(b), 0.0, d)
+
+
+def test_gpu_ptprog_math(ctx):
+    """The device versions of the OptiX-free helpers of pathTracerPrograms.cu (pt_shading.h: the functions shade_hit
+    inlines) against vectors from the reference's own text.  IEEE-only arithmetic (ONB, safeDivide, both Fresnel terms):
+    bit for bit.  The three samplers go through libm (acosf / sinf / cosf: ROCm OCML here, glibc in the vectors) and
+    return unit vectors built from intermediate angles in [0, 2 pi): a libm result that is 1 ulp off moves the angle by
+    up to 2^-23 (ulp of a value in [1, 2)), hence a component by the same absolute amount however small that component
+    is (cos(acos(x)) near x = 0 is the extreme case).  Bar: every component within 2 ulp of itself, or within 2^-22
+    absolute = 2 ulp of the angle it was computed from."""
+    n = G["math_onb_n"].shape[0]
+    cat = lambda *cols: np.concatenate([np.asarray(c, np.float32).reshape(n, -1) for c in cols], axis=1)
+    exact = [
+        (12, cat(G["math_onb_n"], G["math_onb_p"]), 3, G["math_onb_out"], "OrthonormalBasis"),
+        (13, cat(G["math_sdiv_a"], G["math_sdiv_b"]), 3, G["math_sdiv3_out"], "safeDivide"),
+        (17, cat(G["math_fc_cos"], G["math_fc_eta"], G["math_fc_k"]), 3, G["math_fc_out"], "fresnelSchlickConductor"),
+        (18, cat(G["math_fd_cos"], G["math_fd_etai"], G["math_fd_etat"]), 1, G["math_fd_out"].reshape(-1, 1), "FrDielectric"),
+    ]
+    for op, rec, ow, want, name in exact:
+        got = run(ctx, op, rec, n, np.zeros((n, ow), np.float32))
+        assert same_bits_or_both_nan(got, want), name
+    libm = [
+        (14, cat(G["math_u1"], G["math_u2"]), G["math_cosine_out"], "cosine_sample_hemisphere"),
+        (15, cat(G["math_u1"], G["math_u2"]), G["math_uniform_out"], "uniform_sample_hemisphere"),
+        (16, cat(G["math_u1"], G["math_u2"], G["math_ggx_rough"], G["math_onb_n"]), G["math_ggx_out"], "sampleGGX"),
+    ]
+    for op, rec, want, name in libm:
+        got = run(ctx, op, rec, n, np.zeros((n, 3), np.float32))
+        d = ulp_distance(got, want)
+        absd = np.abs(got.astype(np.float64) - want.astype(np.float64))
+        near = absd <= 2.0 ** -22
+        ok = np.isfinite(want).all(axis=1)           # u2 = 1 in sampleGGX divides by zero in the reference too: NaN rows compare as NaN
+        assert np.all((d[ok] <= 2.0) | near[ok]), "%s: max %.1f ulp" % (name, d[ok].max())
+        assert same_bits_or_both_nan(got[~ok], want[~ok]) or np.isnan(got[~ok]).any(axis=1).all(), name
+        print("%s: %.1f%% of components bit-identical, %.2f%% beyond 2 ulp of themselves, max |diff| %.3e" %
+              (name, 100 * (d[ok] == 0).mean(), 100 * (d[ok] > 2).mean(), absd[ok].max()))

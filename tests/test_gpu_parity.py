@@ -17,7 +17,11 @@ from scene_utils import adversarial_rays, copy_params, image_mse, make_params, r
 
 pytestmark = pytest.mark.gpu
 
-MSE_TOL = 1e-3          # north_star: image L2 error vs reference < 1e-3
+# north_star's bar is image L2 error < 1e-3; what is measured is 1e-13 ... 1e-9 (a handful of paths flip where ROCm's and
+# glibc's sinf / cosf / acosf round differently; worst of a 30-camera soak 6e-7, profiles/r01_soak_images.txt).  The
+# tests hold the measured level, not the headline bar: a few-percent error in any shading term is ~1e-4 and fails.
+MSE_TOL = 1e-6
+SAME_BITS_MIN = 0.70    # fraction of pixels whose fp32 accumulation is bit-identical to the oracle's (same summation order)
 _DEFAULT_VARIANT = 1    # render_megakernel.h: kDefaultVariant
 SCENE_FULL = pt.SCENES + "/cornell_box.obj"
 SCENE_DIFFUSE = pt.SCENES + "/cornell_box_diffuse.obj"
@@ -162,7 +166,7 @@ def test_render_config1_diffuse(diffuse):
     mse = image_mse(acc, ref_acc)
     assert mse < MSE_TOL, mse
     same = np.all(acc.view(np.uint32) == ref_acc.view(np.uint32), axis=-1).mean()
-    assert same > 0.60, "only %.3f of the pixels are bit-identical" % same
+    assert same > SAME_BITS_MIN, "only %.3f of the pixels are bit-identical" % same
     assert np.all(acc[..., 3] == 1.0)
     assert (np.abs(fb.astype(int) - ref_fb.astype(int)) <= 1).mean() > 0.995
     s = stats[0]
@@ -170,7 +174,7 @@ def test_render_config1_diffuse(diffuse):
     assert abs(int(s.radiance_rays) - ref_stats["radiance_rays"]) <= 1e-3 * ref_stats["radiance_rays"]
 
 
-@pytest.mark.parametrize("dl,isamp,depth", [(True, True, 8), (False, True, 4), (True, False, 16), (False, False, 28)])
+@pytest.mark.parametrize("dl,isamp,depth", [(True, True, 8), (False, True, 4), (True, False, 16), (False, False, 28), (True, True, 16)])
 def test_render_all_bsdfs(full, dl, isamp, depth):
     """Refractive + conductor + diffuse, every toggle combination, shallow and deep paths."""
     state, obj, sc = full
@@ -181,7 +185,7 @@ def test_render_all_bsdfs(full, dl, isamp, depth):
     mse = image_mse(acc, ref_acc)
     assert mse < MSE_TOL, mse
     same = np.all(acc.view(np.uint32) == ref_acc.view(np.uint32), axis=-1).mean()
-    assert same > 0.50, same     # the rest differ in the last bits: ROCm vs glibc sinf/cosf/acosf
+    assert same > SAME_BITS_MIN, same     # the rest differ in the last bits: ROCm vs glibc sinf/cosf/acosf
     s = stats[0]
     assert s.paths == 128 * 96 * 8
     assert abs(int(s.radiance_rays) - ref_stats["radiance_rays"]) <= 2e-3 * ref_stats["radiance_rays"]
@@ -200,7 +204,7 @@ def test_progressive_accumulation(full):
         q = copy_params(p); q.currentFrameIdx = f
         ref, ref_fb, _, _ = sc.render(q, accumulation=ref, use_bvh=True)
     assert image_mse(acc, ref) < MSE_TOL
-    assert np.all(acc.view(np.uint32) == ref.view(np.uint32), axis=-1).mean() > 0.50
+    assert np.all(acc.view(np.uint32) == ref.view(np.uint32), axis=-1).mean() > SAME_BITS_MIN
 
 
 @pytest.mark.parametrize("chunks", [0, 1, 4])
@@ -288,7 +292,8 @@ def test_fast_math_variant(full):
         assert L.pt_set_tuning(state.context, 0, _DEFAULT_VARIANT) == 0
     ref, _, _, _ = sc.render(copy_params(p), use_bvh=True)
     assert st1[0].paths == st0[0].paths
-    assert image_mse(fast, ref) < MSE_TOL and image_mse(fast, base) < MSE_TOL
+    # other sampler arithmetic -> other low bits everywhere and more flipped paths than the default kernel: its own, looser bar
+    assert image_mse(fast, ref) < 1e-4 and image_mse(fast, base) < 1e-4
     assert not np.array_equal(fast.view(np.uint32), base.view(np.uint32))
     print("fast-math variant: MSE vs oracle %.3e (default %.3e)" % (image_mse(fast, ref), image_mse(base, ref)))
 
@@ -311,7 +316,7 @@ def test_sample_chunks(full, chunks):
                (base_st[0].radiance_rays, base_st[0].shadow_rays, base_st[0].paths, base_st[0].pixels), "same paths, same rays"
         ref, ref_fb, _, _ = sc.render(copy_params(p), use_bvh=True, chunks=used)
         assert image_mse(acc, ref) < MSE_TOL
-        assert np.all(acc.view(np.uint32) == ref.view(np.uint32), axis=-1).mean() > 0.50
+        assert np.all(acc.view(np.uint32) == ref.view(np.uint32), axis=-1).mean() > SAME_BITS_MIN
         rel = np.abs(acc[..., :3] - base[..., :3]) / np.maximum(np.abs(base[..., :3]), 1e-3)
         assert rel.max() < 1e-4, "re-association moves sums by ulps only"
         assert image_mse(acc, base) < 1e-10
@@ -447,6 +452,23 @@ def test_large_scene_properties(gpu_state_factory, oracle, tmp_path):
     ref, _, ref_st, _ = sc.render(copy_params(p), use_bvh=True)
     assert image_mse(acc, ref) < MSE_TOL
     assert abs(int(st[0].radiance_rays) - ref_st["radiance_rays"]) <= 5e-3 * ref_st["radiance_rays"]
+    # BASELINE config 5's own geometry: 1920x1080, 2 x 128 spp, maxDepth 8, IS + DL, automatic sample runs, one batch of
+    # two steps (what bench.py --config 5 times), against the oracle on two windows
+    import oracle_lib
+    assert L.pt_set_sample_chunks(state.context, 0) == 0
+    p = make_params(1920, 1080, 128, 8, True, True)
+    acc, _, st = _gpu_render(state, p, frames=2, fuse=2)
+    assert st[0].paths == 1920 * 1080 * 128 * 2
+    for name, win in (("centre", (944, 500, 32, 32)), ("lower left of the box", (600, 150, 32, 32))):
+        r = None
+        for f in range(2):
+            q = copy_params(p); q.currentFrameIdx = f
+            r, _, _ = oracle_lib.render_window(sc, q, win, accumulation=r, chunks=int(st[0].sample_chunks))
+        x0, y0, ww, wh = win
+        a, rr = acc[y0:y0 + wh, x0:x0 + ww], r[y0:y0 + wh, x0:x0 + ww]
+        print("config 5 / %s: MSE %.3e, mean %.4f" % (name, image_mse(a, rr), float(rr[..., :3].mean())))
+        assert image_mse(a, rr) < MSE_TOL and rr[..., :3].mean() > 0.01
+    assert L.pt_set_sample_chunks(state.context, 1) == 0
 
 
 def test_headless_app_matches_the_python_path(full, tmp_path):
@@ -487,6 +509,69 @@ def test_headless_app_matches_the_python_path(full, tmp_path):
         assert "Total Samples 40" in r.stdout
         outs[fuse] = (open(o, "rb").read(), open(o + ".2.ppm", "rb").read(), open(o + ".4.ppm", "rb").read())
     assert outs[1] == outs[4]
+
+
+# Windows (x0, y0, w, h) of the 1920x1080 frame from the preset camera (image row 0 = bottom, U points to -x): the box
+# front spans columns 431..1489, the ceiling light columns 861..1059 x rows 923..958, the glass sphere 605..840 x 84..320,
+# the metal mesh 1024..1207 x 373..560 (projected from the OBJ).
+HEADLINE_WINDOWS = {
+    "back wall": (900, 500, 48, 48),
+    "glass sphere": (700, 180, 48, 48),
+    "metal mesh": (1090, 440, 48, 48),
+    "light edge": (1036, 915, 48, 48),
+    "box edge (aspect)": (415, 500, 32, 32),
+    "outside the box": (100, 500, 32, 32),
+}
+
+
+def _headline_check(gpu_state_factory, oracle, scene, depth, frames, windows, label):
+    """Full 1920x1080 render (16:9 camera: U scales with the aspect, sutil/Camera.cpp:34-45), 128 spp per step, the
+    library's automatic sample runs and frame batches of 8 — what bench.py times — against the oracle on pixel windows."""
+    import oracle_lib
+    state, obj = gpu_state_factory(scene, sample_chunks=0, width=64, height=64)
+    sc = oracle.scene(obj.getVerticesFloat(), obj.getIndexBuffer(), obj.getMaterialIndices(), obj.getMaterials())
+    W, H, S = 1920, 1080, 128
+    p = make_params(W, H, S, depth, True, True)
+    acc, fb, st = _gpu_render(state, p, frames=frames, fuse=8)
+    chunks = int(st[0].sample_chunks)
+    assert sum(int(t.paths) for t in st) == W * H * S * frames
+    worst = 0.0
+    for name, (x0, y0, ww, wh) in windows.items():
+        ref = None
+        for f in range(frames):
+            q = copy_params(p); q.currentFrameIdx = f
+            ref, _, _ = oracle_lib.render_window(sc, q, (x0, y0, ww, wh), accumulation=ref, chunks=chunks)
+        a, r = acc[y0:y0 + wh, x0:x0 + ww], ref[y0:y0 + wh, x0:x0 + ww]
+        mse = image_mse(a, r)
+        same = float(np.all(a.view(np.uint32) == r.view(np.uint32), axis=-1).mean())
+        rel = float((np.abs(a[..., :3] - r[..., :3]) / np.maximum(np.abs(r[..., :3]), 1e-2)).max())
+        print("%s / %s: MSE %.3e, max rel diff %.3e, %.1f%% pixels bit-identical, mean %.4f" % (label, name, mse, rel, 100 * same, float(r[..., :3].mean())))
+        assert np.all(a[..., 3] == 1.0)
+        assert mse < MSE_TOL, (name, mse)
+        worst = max(worst, mse)
+        if name == "outside the box":
+            assert np.all(a[..., :3] == 0.0) and np.all(r[..., :3] == 0.0)
+        else:
+            assert r[..., :3].mean() > 0.01, "window %s is empty: the camera mapping moved" % name
+        if name == "box edge (aspect)":       # the box front begins at column 431: left part black, right part lit, on both sides
+            assert np.all(r[:, :8, :3] == 0.0) and np.all(a[:, :8, :3] == 0.0) and a[:, 24:, :3].mean() > 0.05
+    sc.close()
+    return worst
+
+
+def test_headline_config2_windows(gpu_state_factory, oracle):
+    """BASELINE config 2 exactly: cornell_box_diffuse.obj, 1920x1080, 8 x 128 = 1024 spp, maxDepth 8, IS + DL."""
+    w = {k: v for k, v in HEADLINE_WINDOWS.items() if k not in ("glass sphere", "metal mesh")}
+    w["short box top"] = (700, 180, 48, 48)
+    _headline_check(gpu_state_factory, oracle, SCENE_DIFFUSE, 8, 8, w, "config 2")
+
+
+def test_headline_config3_windows(gpu_state_factory, oracle):
+    """BASELINE config 3's exact setting (cornell_box.obj with the refractive sphere and the conductor mesh, IS + DL,
+    maxDepth 16) at 1920x1080; 8 of its 32 steps (1024 of 4096 spp) keep the CPU side of the test within a minute."""
+    w = {k: HEADLINE_WINDOWS[k] for k in ("glass sphere", "metal mesh", "light edge")}
+    w = {k: (x, y, 32, 32) for k, (x, y, _, _) in w.items()}
+    _headline_check(gpu_state_factory, oracle, SCENE_FULL, 16, 8, w, "config 3")
 
 
 def test_full_size_properties(diffuse):
@@ -581,15 +666,12 @@ def test_lifetime_and_streams():
     memory; launches enqueued on a caller-provided stream (torch's) are ordered with the caller's work."""
     import torch
     L = _native.hip()
-    for attempt in range(3):          # torch's own device discovery failed once on a box where HIP itself was fine
-        try:
-            torch.cuda.init()
-            break
-        except RuntimeError:
-            if attempt == 2:
-                raise
-            import time
-            time.sleep(2.0)
+    try:
+        torch.cuda.init()
+    except RuntimeError as e:         # no retry: report what the box looks like and fail
+        import subprocess
+        diag = subprocess.run("rocminfo | head -40; ls -l /dev/kfd /dev/dri", shell=True, capture_output=True, text=True).stdout
+        raise AssertionError("torch.cuda.init() failed: %s\n%s" % (e, diag))
     obj = pt.TinyObjWrapper(SCENE_FULL)
     free0 = None
     for it in range(7):
