@@ -37,12 +37,14 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def build_hip(force=False, verbose=False):
-    out = os.path.join(PKG, "libacgpt_hip.so")
+def build_hip(force=False, verbose=False, experiments=False):
+    """experiments=True builds libacgpt_hip_exp.so: the same library plus every kernel variant that was measured and
+    not adopted (-DACGPT_EXPERIMENTS; tools/sweep_variants.py loads it via ACGPT_EXPERIMENTS=1).  Never the product."""
+    out = os.path.join(PKG, "libacgpt_hip_exp.so" if experiments else "libacgpt_hip.so")
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     deps = srcs + [os.path.join(CSRC, h) for h in HIP_HEADERS] + [os.path.join(ROOT, "include", "acgpt.h")]
     if force or _stale(out, deps):
-        cmd = [_hipcc()] + HIP_FLAGS + ["-o", out] + srcs
+        cmd = [_hipcc()] + HIP_FLAGS + (["-DACGPT_EXPERIMENTS"] if experiments else []) + ["-o", out] + srcs
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT if not verbose else None)

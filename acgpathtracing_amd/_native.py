@@ -54,7 +54,8 @@ class BvhInfo(C.Structure):
     _fields_ = [("n_tris", C.c_uint32), ("n_nodes", C.c_uint32), ("max_depth", C.c_uint32), ("stack_entries", C.c_uint32),
                 ("scene_lo", C.c_float * 3), ("scene_hi", C.c_float * 3), ("build_ms", C.c_float),
                 ("node_bytes", C.c_uint32), ("tri_bytes", C.c_uint32),
-                ("wide_nodes", C.c_uint32), ("wide_depth", C.c_uint32), ("wide_bytes", C.c_uint32), ("wide_ms", C.c_float)]
+                ("wide_nodes", C.c_uint32), ("wide_depth", C.c_uint32), ("wide_bytes", C.c_uint32), ("wide_ms", C.c_float),
+                ("half_node_bytes", C.c_uint32), ("half_area_ratio", C.c_float)]
 
 
 assert C.sizeof(PathTraceParams) == 168
@@ -75,6 +76,10 @@ _host = None
 
 
 def hip_library_path():
+    # ACGPT_EXPERIMENTS=1 (tools/sweep_variants.py only): the build that also carries the kernel variants that were
+    # measured and not adopted.  Same sources, same ABI; never what tests, smoke() or bench.py load by default.
+    if os.environ.get("ACGPT_EXPERIMENTS") == "1":
+        return os.path.join(PKG, "libacgpt_hip_exp.so")
     return os.path.join(PKG, "libacgpt_hip.so")
 
 

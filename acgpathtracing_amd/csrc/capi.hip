@@ -117,6 +117,13 @@ PT_API void pt_destroy(pt_ctx* c)
     delete c;
 }
 
+static int pick_variant(const pt_ctx* c)
+{
+    const bool half_ok = c->bvh.half_area_ratio <= ptd::kHalfAreaLimit;
+    const bool large = c->bvh.n_tris > ptd::kLargeSceneTris;
+    return half_ok ? (large ? ptd::kVariantF16Large : ptd::kVariantF16) : (large ? ptd::kVariantF32Large : ptd::kVariantF32);
+}
+
 // dwords per lane: one push per internal node on a root-to-leaf path at most (two-child tree), or one
 // 8-byte group per level (four-wide tree, if built); every kernel variant gets the larger of the two
 static int size_stack(pt_ctx* c)
@@ -165,7 +172,7 @@ PT_API int pt_set_scene(pt_ctx* c, const float* verts_xyzw, size_t n_verts, cons
         CK(c, hipMemcpy(c->d_mats, mats, n_mats * sizeof(pt_material), hipMemcpyHostToDevice));
     }
     c->n_mats = (uint32_t)n_mats;
-    if (c->variant_auto) c->variant = c->bvh.n_tris > ptd::kLargeSceneTris ? ptd::kLargeSceneVariant : ptd::kDefaultVariant;
+    if (c->variant_auto) c->variant = pick_variant(c);
     if (int rc = size_stack(c)) return rc;
     if (ptd::render_variant_node_format(c->variant) == 3) { if (int rc = ensure_wide(c)) return rc; }
     c->scene_serial++;
@@ -190,6 +197,8 @@ PT_API int pt_get_bvh_info(pt_ctx* c, pt_bvh_info* out)
     out->wide_depth = c->bvh.wide_depth;
     out->wide_bytes = c->bvh.n_wrecs * 48u;
     out->wide_ms = c->bvh.wide_ms;
+    out->half_node_bytes = c->bvh.n_nodes * (uint32_t)sizeof(ptd::HNode);
+    out->half_area_ratio = c->bvh.half_area_ratio;
     return 0;
 }
 
@@ -213,12 +222,12 @@ PT_API int pt_set_tuning(pt_ctx* c, int blocks_per_cu, int variant)
 {
     if (!c) return fail(nullptr, "pt_set_tuning: null context");
     if (blocks_per_cu < 0 || blocks_per_cu > 16) return fail(c, "pt_set_tuning: blocks_per_cu out of range");
-    if (variant < 0 || variant >= ptd::render_variant_count()) return fail(c, "pt_set_tuning: unknown kernel variant");
+    if (variant < -1 || variant >= ptd::render_variant_count()) return fail(c, "pt_set_tuning: unknown kernel variant");
     CK(c, hipSetDevice(c->device));
     c->tune_blocks_per_cu = blocks_per_cu;
-    c->variant = variant;
-    c->variant_auto = false;
-    if (ptd::render_variant_node_format(variant) == 3) { if (int rc = ensure_wide(c)) return rc; }
+    c->variant_auto = variant < 0;
+    c->variant = variant < 0 ? pick_variant(c) : variant;
+    if (ptd::render_variant_node_format(c->variant) == 3) { if (int rc = ensure_wide(c)) return rc; }
     CK(c, ptd::render_occupancy(c->variant, c->stack_entries, c->bvh.n_nodes, &c->blocks_per_cu));
     if (c->blocks_per_cu < 1) return fail(c, "pt_set_tuning: this kernel variant does not fit the current scene in LDS");
     return 0;
@@ -247,7 +256,7 @@ PT_API int pt_set_stream(pt_ctx* c, void* s)
 static ptd::DeviceScene device_scene(pt_ctx* c)
 {
     ptd::DeviceScene sc;
-    sc.nodes = c->bvh.nodes; sc.qnodes = c->bvh.qnodes; sc.cnodes = c->bvh.cnodes; sc.grid = c->bvh.grid; sc.tris = c->bvh.tris; sc.wrecs = c->bvh.wrecs; sc.mats = c->d_mats;
+    sc.nodes = c->bvh.nodes; sc.qnodes = c->bvh.qnodes; sc.cnodes = c->bvh.cnodes; sc.hnodes = c->bvh.hnodes; sc.hspace = c->bvh.hspace; sc.grid = c->bvh.grid; sc.tris = c->bvh.tris; sc.wrecs = c->bvh.wrecs; sc.mats = c->d_mats;
     sc.n_tris = c->bvh.n_tris; sc.n_mats = c->n_mats;
     return sc;
 }
@@ -448,7 +457,7 @@ PT_API int pt_trace_any(pt_ctx* c, const float* rays, size_t n, uint8_t* hit_out
 PT_API int pt_bench_traversal(pt_ctx* c, const float* rays, size_t n, int repeats, int node_format, float* t_out, uint32_t* prim_out, float* ms_out,
                               uint64_t* counters_out)
 {
-    if (!c || !rays || !t_out || !prim_out || !ms_out || n == 0 || n > 0x7FFFFFFFull || repeats < 1 || node_format < 0 || node_format > 2)
+    if (!c || !rays || !t_out || !prim_out || !ms_out || n == 0 || n > 0x7FFFFFFFull || repeats < 1 || node_format < 0 || node_format > 3)
         return fail(c, "pt_bench_traversal: bad argument");
     if (node_format == 1) { if (int rc = ensure_wide(c)) return rc; }
     const uint32_t entries = node_format == 1 ? (c->bvh.wide_depth + 1u) : c->stack_entries;

@@ -12,6 +12,9 @@ struct LbvhResult {
     BvhNode*   nodes = nullptr;        // device, n_nodes (fp32 boxes, 64 B)
     QNode*     qnodes = nullptr;       // device, n_nodes (16-bit grid boxes, 32 B)
     BvhNode*   cnodes = nullptr;       // device, n_nodes (centre + half-extent boxes, 64 B)
+    HNode*     hnodes = nullptr;       // device, n_nodes (fp16 boxes, 32 B)
+    HSpace     hspace = {0, 0, 0, 1};
+    float      half_area_ratio = 0.0f; // sum of child-box areas after fp16 outward rounding / before: how much the coarser planes cost
     QGrid      grid = {};              // world -> grid transform of qnodes
     TriRecord* tris = nullptr;         // device, n_tris, Morton order
     uint4*     wrecs = nullptr;        // device, n_wrecs x 48 B: four-wide nodes + triangles (wide_bvh.hip)

@@ -14,6 +14,7 @@
 // given triangle list.
 #include "pt_device.h"
 #include "lbvh_build.h"
+#include <hip/hip_fp16.h>
 #include <vector>
 
 namespace ptd {
@@ -455,6 +456,47 @@ __global__ void k_centre_nodes(const BvhNode* __restrict__ nodes, uint32_t n, Bv
     cn[i] = o;
 }
 
+// --- 8. fp16 copy of the nodes -------------------------------------------------------------------------
+// Planes go to the scene-centred, power-of-two scaled space of HSpace and are rounded OUTWARD to fp16 (lo down, hi up),
+// so every fp16 box contains its fp32 box.  area[0] / area[1] accumulate the child-box surface areas before / after,
+// the measure by which pt_set_scene decides whether the coarser planes are acceptable for this scene.
+__device__ __forceinline__ uint32_t half_bits(__half h) { return (uint32_t)__half_as_ushort(h); }
+__device__ __forceinline__ uint32_t pack_planes(float lo, float hi, float c, float scale, float& glo, float& ghi)
+{
+    if (!(lo <= hi)) { glo = 0.0f; ghi = 0.0f; return 0x7C00u | (0xFC00u << 16); }      // empty child: lo = +inf, hi = -inf
+    // (w - c) * scale rounds twice in fp32; one extra fp16 step outward covers that
+    const float a = (lo - c) * scale, b = (hi - c) * scale;
+    __half hl = __float2half_rd(a - fabsf(a) * 2e-7f), hh = __float2half_ru(b + fabsf(b) * 2e-7f);
+    glo = __half2float(hl); ghi = __half2float(hh);
+    return half_bits(hl) | (half_bits(hh) << 16);
+}
+__global__ void k_half_nodes(const BvhNode* __restrict__ nodes, uint32_t n, HSpace sp, HNode* __restrict__ hn, float* __restrict__ area)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float before = 0.0f, after = 0.0f;
+    if (i < n) {
+        const BvhNode nd = nodes[i];
+        const float scale = 1.0f / sp.inv_scale;
+        float l[6], h[6];
+        HNode o;
+        // child 0: lo (a.x a.y a.z) hi (a.w b.x b.y); child 1: lo (b.z b.w c.x) hi (c.y c.z c.w)
+        o.a = make_uint4(pack_planes(nd.a.x, nd.a.w, sp.cx, scale, l[0], h[0]), pack_planes(nd.a.y, nd.b.x, sp.cy, scale, l[1], h[1]),
+                         pack_planes(nd.a.z, nd.b.y, sp.cz, scale, l[2], h[2]), (uint32_t)nd.d.x);
+        o.b = make_uint4(pack_planes(nd.b.z, nd.c.y, sp.cx, scale, l[3], h[3]), pack_planes(nd.b.w, nd.c.z, sp.cy, scale, l[4], h[4]),
+                         pack_planes(nd.c.x, nd.c.w, sp.cz, scale, l[5], h[5]), (uint32_t)nd.d.y);
+        hn[i] = o;
+        const float e0[3] = {nd.a.w - nd.a.x, nd.b.x - nd.a.y, nd.b.y - nd.a.z}, e1[3] = {nd.c.y - nd.b.z, nd.c.z - nd.b.w, nd.c.w - nd.c.x};
+        if (e0[0] >= 0.0f) before += e0[0] * e0[1] + e0[1] * e0[2] + e0[2] * e0[0];
+        if (e1[0] >= 0.0f) before += e1[0] * e1[1] + e1[1] * e1[2] + e1[2] * e1[0];
+        const float g0[3] = {(h[0] - l[0]) * sp.inv_scale, (h[1] - l[1]) * sp.inv_scale, (h[2] - l[2]) * sp.inv_scale};
+        const float g1[3] = {(h[3] - l[3]) * sp.inv_scale, (h[4] - l[4]) * sp.inv_scale, (h[5] - l[5]) * sp.inv_scale};
+        if (e0[0] >= 0.0f) after += g0[0] * g0[1] + g0[1] * g0[2] + g0[2] * g0[0];
+        if (e1[0] >= 0.0f) after += g1[0] * g1[1] + g1[1] * g1[2] + g1[2] * g1[0];
+    }
+    for (int off = 32; off > 0; off >>= 1) { before += __shfl_xor(before, off); after += __shfl_xor(after, off); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&area[0], before); atomicAdd(&area[1], after); }
+}
+
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); return false; } } while (0)
 
 namespace {
@@ -482,6 +524,7 @@ void free_lbvh(LbvhResult& r)
     if (r.nodes) (void)hipFree(r.nodes);
     if (r.qnodes) (void)hipFree(r.qnodes);
     if (r.cnodes) (void)hipFree(r.cnodes);
+    if (r.hnodes) (void)hipFree(r.hnodes);
     if (r.tris) (void)hipFree(r.tris);
     if (r.wrecs) (void)hipFree(r.wrecs);
     if (r.keys_sorted) (void)hipFree(r.keys_sorted);
@@ -527,6 +570,7 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
     HIPCK(hipMalloc((void**)&out.nodes, (size_t)n_nodes * sizeof(BvhNode)));
     HIPCK(hipMalloc((void**)&out.qnodes, (size_t)n_nodes * sizeof(QNode)));
     HIPCK(hipMalloc((void**)&out.cnodes, (size_t)n_nodes * sizeof(BvhNode)));
+    HIPCK(hipMalloc((void**)&out.hnodes, (size_t)n_nodes * sizeof(HNode)));
     HIPCK(hipMalloc((void**)&out.tris, (size_t)n * sizeof(TriRecord)));
     HIPCK(hipMalloc((void**)&out.keys_sorted, (size_t)n * 4));
     HIPCK(hipMalloc((void**)&out.vals_sorted, (size_t)n * 4));
@@ -604,6 +648,25 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
     HIPCK(hipStreamSynchronize(stream));
     HIPCK(hipEventElapsedTime(&out.build_ms, sc.ev0, sc.ev1));
     for (int k = 0; k < 3; k++) { out.scene_lo[k] = ord2f(h_bounds[k]); out.scene_hi[k] = ord2f(h_bounds[3 + k]); }
+    {   // fp16 nodes: centre of the scene box, power-of-two scale that puts the farthest plane in [512, 1024)
+        float half_ext = 0.0f;
+        HSpace sp;
+        float* cc = &sp.cx;
+        for (int k = 0; k < 3; k++) { cc[k] = 0.5f * out.scene_lo[k] + 0.5f * out.scene_hi[k]; half_ext = fmaxf(half_ext, fmaxf(out.scene_hi[k] - cc[k], cc[k] - out.scene_lo[k])); }
+        int e = 0;
+        (void)frexpf(half_ext > 0.0f && half_ext < INFINITY ? half_ext : 1.0f, &e);      // half_ext = m * 2^e, m in [0.5, 1)
+        sp.inv_scale = ldexpf(1.0f, e - 10);                                             // g = w * 2^(10 - e): |g| < 1024
+        float* d_area;
+        float h_area[2] = {0.0f, 0.0f};
+        HIPCK(sc.alloc(&d_area, 8));
+        HIPCK(hipMemsetAsync(d_area, 0, 8, stream));
+        k_half_nodes<<<(n_nodes + 255) / 256, 256, 0, stream>>>(out.nodes, n_nodes, sp, out.hnodes, d_area);
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(h_area, d_area, 8, hipMemcpyDeviceToHost, stream));
+        HIPCK(hipStreamSynchronize(stream));
+        out.hspace = sp;
+        out.half_area_ratio = h_area[0] > 0.0f ? h_area[1] / h_area[0] : 1.0f;
+    }
     out.n_nodes = n_nodes;
     out.max_depth = (uint32_t)root_hi.w;
     out.grid = make_qgrid_f(out.scene_lo, out.scene_hi);

@@ -44,6 +44,19 @@ struct __attribute__((aligned(16))) QNode {
 };
 static_assert(sizeof(QNode) == 32, "qnode size");
 
+// Half-precision node, 32 B = two 16-byte loads: each child box as six fp16 planes in a scene-centred, power-of-two
+// scaled space g = (w - centre) * scale, lo rounded down and hi rounded up so the fp16 box contains the fp32 one.
+//   a = { lo0.x | hi0.x << 16, lo0.y | hi0.y << 16, lo0.z | hi0.z << 16, child0 }
+//   b = { lo1.x | hi1.x << 16, lo1.y | hi1.y << 16, lo1.z | hi1.z << 16, child1 }
+// A slab plane is t = g * (1/d / scale) + (centre - o)/d: one v_fma_mix_f32 per plane, which reads the fp16 half of the
+// register directly — the decode costs no instruction, the node half the loads of the fp32 format.
+struct __attribute__((aligned(16))) HNode {
+    uint4 a;
+    uint4 b;
+};
+static_assert(sizeof(HNode) == 32, "hnode size");
+struct HSpace { float cx, cy, cz, inv_scale; };     // world = g * inv_scale + centre; inv_scale is a power of two
+
 // world -> grid: g = (w - origin) * inv_cell ; cell sizes per axis
 struct QGrid {
     float ox, oy, oz;
@@ -55,6 +68,8 @@ struct DeviceScene {
     const BvhNode*     nodes;
     const QNode*       qnodes;
     const BvhNode*     cnodes;    // the same tree with every child box as centre + half extent (layout of BvhNode: lo -> centre, hi -> half extent)
+    const HNode*       hnodes;    // the same tree with fp16 boxes (32-byte nodes)
+    HSpace             hspace;
     QGrid              grid;
     const TriRecord*   tris;
     const uint4*       wrecs;     // four-wide tree: 48-byte records, wide nodes and triangles in one array (wide_bvh.hip)
@@ -181,6 +196,11 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 // +-1e30 a zero direction component still sends both planes to +-huge with the signs of (p - o), up to the rounding of
 // o/d that lbvh_build.hip's pad_abs covers.
 __device__ __forceinline__ float finite_rcp(float x) { return fminf(fmaxf(__builtin_amdgcn_rcpf(x), -1e30f), 1e30f); }
+
+// fp16 plane (low / high half of a packed dword) times a, plus b, in fp32: compiles to one v_fma_mix_f32
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float fma_h_lo(uint32_t packed, float a, float b) { return __builtin_fmaf((float)__builtin_bit_cast(half2_t, packed).x, a, b); }
+__device__ __forceinline__ float fma_h_hi(uint32_t packed, float a, float b) { return __builtin_fmaf((float)__builtin_bit_cast(half2_t, packed).y, a, b); }
 
 // ------------------------------------------------------------ wave votes ----
 // __ballot(int) first turns the predicate into 0 / 1 in a VGPR and compares it again (two half-rate vector

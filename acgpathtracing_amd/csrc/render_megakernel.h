@@ -7,9 +7,14 @@ namespace ptd {
 
 constexpr int kRenderThreads = 256;   // 4 waves per workgroup (segment-synchronous variant)
 constexpr uint32_t kMaxTimedWaves = 16384;   // stats variants stamp start / queue-empty / end per wave behind the 8 counters
-constexpr int kDefaultVariant = 1;    // persistent traversal, K44 L16, two visits and two triangle tests per loop trip, fp32 nodes, 4 waves/SIMD (no spills)
-constexpr int kLargeSceneVariant = 16;   // the same with triangle rounds at 8 lanes: 3 % faster once the tree outgrows the caches
+// Variant indices of the product library (render_megakernel.hip kVariants).  pt_set_scene picks one per scene unless
+// pt_set_tuning named one: fp16 nodes when the fp16 planes cost less than kHalfAreaLimit in summed child-box area (every
+// Cornell-class scene), fp32 nodes otherwise; above kLargeSceneTris the shape with triangle rounds at 8 lanes.
+constexpr int kVariantSync = 0, kVariantF32 = 1, kVariantF32Stats = 2, kVariantF32Large = 3, kVariantFastMath = 4;
+constexpr int kVariantF16 = 5, kVariantF16Stats = 6, kVariantF16Large = 5;   // one shape serves both sizes (profiles/r02_sweep_*)
+constexpr int kDefaultVariant = kVariantF16;
 constexpr uint32_t kLargeSceneTris = 100000;
+constexpr float kHalfAreaLimit = 1.05f;
 
 struct RenderArgs {
     DeviceScene scene;
@@ -46,7 +51,7 @@ struct RenderArgs {
 int render_variant_count();
 const char* render_variant_name(int variant);
 int render_variant_threads(int variant);
-int render_variant_node_format(int variant);   // 0 fp32 two-child, 1/2 16-bit two-child, 3 four-wide 8-bit
+int render_variant_node_format(int variant);   // 0 fp32 two-child, 7 fp16 two-child; experiments: 1/2/4 16-bit grid, 3 four-wide 8-bit
 hipError_t render_occupancy(int variant, uint32_t stack_entries, uint32_t n_nodes, int* blocks_per_cu);
 hipError_t launch_render(int variant, const RenderArgs& args, uint32_t grid_blocks, hipStream_t stream);
 hipError_t launch_items(const RenderArgs& args, hipStream_t stream);

@@ -302,6 +302,38 @@ k_render(const RenderArgs A)
     }
 }
 
+// Per-ray constants of the slab test for node format NODE_FMT (see k_render_pw): rinv multiplies a stored plane, gro is added.
+// NODE_FMT 8 keeps, per axis, a rotate amount (0 or 16): the packed fp16 pair {lo, hi} of a node is rotated so that the
+// low half is the plane the ray meets first.  Near and far planes then need no per-axis min / max.
+struct AxisRot { uint32_t x, y, z; };
+__device__ __forceinline__ AxisRot axis_rot(const f3& rinv)
+{
+    AxisRot r;
+    r.x = rinv.x < 0.0f ? 16u : 0u; r.y = rinv.y < 0.0f ? 16u : 0u; r.z = rinv.z < 0.0f ? 16u : 0u;
+    return r;
+}
+__device__ __forceinline__ uint32_t rot16(uint32_t v, uint32_t by) { return __builtin_amdgcn_alignbit(v, v, by); }
+
+template <int NODE_FMT>
+__device__ __forceinline__ void setup_ray(const f3& ro, const f3& rd, const QGrid& G, const HSpace& HS, f3& rinv, f3& gro)
+{
+    if (NODE_FMT == 0 || NODE_FMT == 6) {            // t = p * (1/d) + (-o/d)
+        rinv = mk(finite_rcp(rd.x), finite_rcp(rd.y), finite_rcp(rd.z));
+        gro = mk(-(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z));
+    } else if (NODE_FMT == 7 || NODE_FMT == 8) {     // t = g * (1/d / scale) + (centre - o)/d, g = the fp16 plane
+        const f3 r = mk(finite_rcp(rd.x), finite_rcp(rd.y), finite_rcp(rd.z));
+        gro = mk((HS.cx - ro.x) * r.x, (HS.cy - ro.y) * r.y, (HS.cz - ro.z) * r.z);
+        rinv = r * HS.inv_scale;
+    } else {
+        rinv = mk(fast_rcp(rd.x), fast_rcp(rd.y), fast_rcp(rd.z));
+        if (NODE_FMT == 1 || NODE_FMT == 2 || NODE_FMT == 4) {
+            gro = mk((ro.x - G.ox) * G.icx, (ro.y - G.oy) * G.icy, (ro.z - G.oz) * G.icz);
+            rinv = mk(G.cx * rinv.x, G.cy * rinv.y, G.cz * rinv.z);
+            if (NODE_FMT == 4) gro = mk(-(gro.x * rinv.x), -(gro.y * rinv.y), -(gro.z * rinv.z));   // t = q * rinv + gro
+        }
+    }
+}
+
 // =================================================================================================
 // Variant 1: persistent traversal with deferred shading.  The BVH loop never waits for the slowest
 // ray: a lane whose ray is finished parks; once SHADE_K lanes are parked (or nothing is left to
@@ -313,6 +345,8 @@ k_render(const RenderArgs A)
 // LEAF_K: triangle tests run when at least LEAF_K lanes sit at a leaf, or no lane has an inner node.
 // =================================================================================================
 // NODE_FMT: 0 = fp32 boxes, 64-byte nodes in global memory (4 x 16-byte loads per visit), slab test as one fma per plane
+//           7 = fp16 boxes in a scene-centred space, 32-byte nodes (2 loads per visit), the same fma count: each plane is a
+//               v_fma_mix_f32 reading the fp16 half in place (pt_device.h HNode)
 //           5 = the same nodes, slab test as subtract + multiply per plane
 //           4 = 16-bit grid nodes with the fma form
 //           1 = 16-bit grid boxes, 32-byte nodes in global memory (2 loads per visit)
@@ -345,6 +379,7 @@ k_render_pw(const RenderArgs A)
         __syncthreads();
     }
     const QGrid G = sc.grid;
+    const HSpace HS = sc.hspace;
     const ShadeConsts K = shade_consts(A);
     const f3 eye = mk(A.eye), camU = mk(A.U), camV = mk(A.V), camW = mk(A.W);
     const float fw = (float)(int)A.width, fh = (float)(int)A.height;
@@ -364,6 +399,7 @@ k_render_pw(const RenderArgs A)
     f3 att = mk(1.0f);
     // ray in flight (rinv / gro: reciprocal direction and origin, in grid space for quantised nodes)
     f3 ro = mk(0.0f), rd = mk(0.0f, 0.0f, 1.0f), rinv = mk(1.0f), gro = mk(0.0f);
+    AxisRot rot = {0u, 0u, 0u};                       // NODE_FMT 8 only
     constexpr float rtmin = 0.01f;      // both ray kinds start at 0.01 (:750-757 and :660-672): a literal, not a register
     float rtmax = 0.0f, best_t = 0.0f;
     int best_slot = -1; uint32_t best_prim = 0xFFFFFFFFu;
@@ -394,13 +430,8 @@ k_render_pw(const RenderArgs A)
                 lp.result += emission;                                // :760 (before the radiance term)
                 if (want_shadow) {
                     ro = P; rd = L;
-                    rinv = (NODE_FMT == 0 || NODE_FMT == 6) ? mk(finite_rcp(L.x), finite_rcp(L.y), finite_rcp(L.z)) : mk(fast_rcp(L.x), fast_rcp(L.y), fast_rcp(L.z));
-                    if (NODE_FMT == 0 || NODE_FMT == 6) gro = mk(-(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z));
-                    if (NODE_FMT == 1 || NODE_FMT == 2 || NODE_FMT == 4) {
-                        gro = mk((ro.x - G.ox) * G.icx, (ro.y - G.oy) * G.icy, (ro.z - G.oz) * G.icz);
-                        rinv = mk(G.cx * rinv.x, G.cy * rinv.y, G.cz * rinv.z);
-                        if (NODE_FMT == 4) gro = mk(-(gro.x * rinv.x), -(gro.y * rinv.y), -(gro.z * rinv.z));   // t = q * rinv + gro
-                    }
+                    setup_ray<NODE_FMT>(ro, rd, G, HS, rinv, gro);
+                    if (NODE_FMT == 8) rot = axis_rot(rinv);
                     rtmax = Ldist - 0.01f; best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu;
                     node = root; sp = 0; cur_list = 0u; shadow_ray = true; shadow_hit = false; started_shadow = true;
                 } else {
@@ -447,13 +478,8 @@ k_render_pw(const RenderArgs A)
             start_radiance = true;
         }
         if (start_radiance) {                                         // traceRadiance :750-757
-            rinv = (NODE_FMT == 0 || NODE_FMT == 6) ? mk(finite_rcp(rd.x), finite_rcp(rd.y), finite_rcp(rd.z)) : mk(fast_rcp(rd.x), fast_rcp(rd.y), fast_rcp(rd.z));
-            if (NODE_FMT == 0 || NODE_FMT == 6) gro = mk(-(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z));
-            if (NODE_FMT == 1 || NODE_FMT == 2 || NODE_FMT == 4) {
-                gro = mk((ro.x - G.ox) * G.icx, (ro.y - G.oy) * G.icy, (ro.z - G.oz) * G.icz);
-                rinv = mk(G.cx * rinv.x, G.cy * rinv.y, G.cz * rinv.z);
-                if (NODE_FMT == 4) gro = mk(-(gro.x * rinv.x), -(gro.y * rinv.y), -(gro.z * rinv.z));
-            }
+            setup_ray<NODE_FMT>(ro, rd, G, HS, rinv, gro);
+            if (NODE_FMT == 8) rot = axis_rot(rinv);
             rtmax = 1e16f; best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu;
             node = root; sp = 0; cur_list = 0u; shadow_ray = false;
         }
@@ -548,6 +574,33 @@ k_render_pw(const RenderArgs A)
                     const float w0 = __builtin_fmaf(c.x, rinv.z, gro.z), w1 = __builtin_fmaf(c.w, rinv.z, gro.z);
                     n1 = fmaxf(fmaxf(fminf(u0, u1), fminf(v0, v1)), fmaxf(fminf(w0, w1), rtmin));
                     f1 = fminf(fminf(fmaxf(u0, u1), fmaxf(v0, v1)), fmaxf(w0, w1)) * kFarWiden;
+                } else if (NODE_FMT == 7) {
+                    // fp16 planes, two 16-byte loads; every plane is one v_fma_mix_f32 (the fp16 -> fp32 conversion is part of it)
+                    const uint4* np = (const uint4*)((const char*)sc.hnodes + (size_t)((uint32_t)node << 5));
+                    const uint4 qa = np[0], qb = np[1];
+                    c0 = (int)qa.w; c1 = (int)qb.w;
+                    const float x0 = fma_h_lo(qa.x, rinv.x, gro.x), x1 = fma_h_hi(qa.x, rinv.x, gro.x);
+                    const float y0 = fma_h_lo(qa.y, rinv.y, gro.y), y1 = fma_h_hi(qa.y, rinv.y, gro.y);
+                    const float z0 = fma_h_lo(qa.z, rinv.z, gro.z), z1 = fma_h_hi(qa.z, rinv.z, gro.z);
+                    n0 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), rtmin));
+                    f0 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1)) * kFarWiden;
+                    const float u0 = fma_h_lo(qb.x, rinv.x, gro.x), u1 = fma_h_hi(qb.x, rinv.x, gro.x);
+                    const float v0 = fma_h_lo(qb.y, rinv.y, gro.y), v1 = fma_h_hi(qb.y, rinv.y, gro.y);
+                    const float w0 = fma_h_lo(qb.z, rinv.z, gro.z), w1 = fma_h_hi(qb.z, rinv.z, gro.z);
+                    n1 = fmaxf(fmaxf(fminf(u0, u1), fminf(v0, v1)), fmaxf(fminf(w0, w1), rtmin));
+                    f1 = fminf(fminf(fmaxf(u0, u1), fmaxf(v0, v1)), fmaxf(w0, w1)) * kFarWiden;
+                } else if (NODE_FMT == 8) {
+                    // fp16 planes as NODE_FMT 7; each packed {lo, hi} pair is rotated by the ray's per-axis amount first, so the
+                    // low half is always the near plane: 6 rotates replace 12 min / max
+                    const uint4* np = (const uint4*)((const char*)sc.hnodes + (size_t)((uint32_t)node << 5));
+                    const uint4 qa = np[0], qb = np[1];
+                    c0 = (int)qa.w; c1 = (int)qb.w;
+                    const uint32_t ax = rot16(qa.x, rot.x), ay = rot16(qa.y, rot.y), az = rot16(qa.z, rot.z);
+                    n0 = fmaxf(fmaxf(fma_h_lo(ax, rinv.x, gro.x), fma_h_lo(ay, rinv.y, gro.y)), fmaxf(fma_h_lo(az, rinv.z, gro.z), rtmin));
+                    f0 = fminf(fminf(fma_h_hi(ax, rinv.x, gro.x), fma_h_hi(ay, rinv.y, gro.y)), fma_h_hi(az, rinv.z, gro.z)) * kFarWiden;
+                    const uint32_t bx = rot16(qb.x, rot.x), by = rot16(qb.y, rot.y), bz = rot16(qb.z, rot.z);
+                    n1 = fmaxf(fmaxf(fma_h_lo(bx, rinv.x, gro.x), fma_h_lo(by, rinv.y, gro.y)), fmaxf(fma_h_lo(bz, rinv.z, gro.z), rtmin));
+                    f1 = fminf(fminf(fma_h_hi(bx, rinv.x, gro.x), fma_h_hi(by, rinv.y, gro.y)), fma_h_hi(bz, rinv.z, gro.z)) * kFarWiden;
                 } else if (NODE_FMT == 6) {
                     // centre / half-extent nodes: near = (c - o)/d - h/|d|, far = (c - o)/d + h/|d|: full-rate arithmetic only,
                     // the |.| is a source modifier
@@ -760,7 +813,7 @@ k_trace_any(const DeviceScene sc, uint32_t stack_entries, const float* __restric
 // grant).  No path state, no shading: few registers, full occupancy, lanes (almost) never idle.  It
 // answers one question — how fast could traversal alone go on this scene and ray mix — and is
 // bit-checked against pt_trace_closest / pt_trace_any.
-template <int FETCH_K, int LEAF_K, bool FMA_SLAB = false>
+template <int FETCH_K, int LEAF_K, int FMT = 0>
 __global__ void __launch_bounds__(256)
 k_trace_stream(const DeviceScene sc, uint32_t stack_entries, const float4* __restrict__ rays, uint32_t n,
                uint32_t* __restrict__ head, float* __restrict__ t_out, uint32_t* __restrict__ prim_out,
@@ -810,8 +863,9 @@ k_trace_stream(const DeviceScene sc, uint32_t stack_entries, const float4* __res
                     const float4 a = rays[2ull * rid], b = rays[2ull * rid + 1];
                     ro = mk(a.x, a.y, a.z); rd = mk(a.w, b.x, b.y); rtmin = b.z;
                     any_ray = b.w < 0.0f; rtmax = fabsf(b.w);
-                    rinv = FMA_SLAB ? mk(finite_rcp(rd.x), finite_rcp(rd.y), finite_rcp(rd.z)) : mk(fast_rcp(rd.x), fast_rcp(rd.y), fast_rcp(rd.z));
-                    if (FMA_SLAB) roi = mk(-(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z));
+                    if (FMT == 2) setup_ray<0>(ro, rd, sc.grid, sc.hspace, rinv, roi);
+                    else if (FMT == 3) setup_ray<7>(ro, rd, sc.grid, sc.hspace, rinv, roi);
+                    else rinv = mk(fast_rcp(rd.x), fast_rcp(rd.y), fast_rcp(rd.z));
                     best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu; any_hit = false;
                     node = sc.n_tris ? 0 : kSentinel; sp = 0;
                 }
@@ -826,11 +880,23 @@ k_trace_stream(const DeviceScene sc, uint32_t stack_entries, const float4* __res
         // one traversal step
         { const unsigned long long vm = vote(node >= 0 && node != kSentinel); n_iter++; n_visit += (unsigned long long)popc(vm); n_vround += vm ? 1u : 0u; }
         if (node >= 0 && node != kSentinel) {
+            float x0, x1, y0, y1, z0, z1, u0, u1, v0, v1, w0, w1;
+            int2 ch;
+            if (FMT == 3) {        // fp16 nodes, two loads, v_fma_mix_f32 planes: the render kernel's NODE_FMT 7
+                const uint4* hp = (const uint4*)(sc.hnodes + node);
+                const uint4 qa = hp[0], qb = hp[1];
+                ch = make_int2((int)qa.w, (int)qb.w);
+                x0 = fma_h_lo(qa.x, rinv.x, roi.x); x1 = fma_h_hi(qa.x, rinv.x, roi.x);
+                y0 = fma_h_lo(qa.y, rinv.y, roi.y); y1 = fma_h_hi(qa.y, rinv.y, roi.y);
+                z0 = fma_h_lo(qa.z, rinv.z, roi.z); z1 = fma_h_hi(qa.z, rinv.z, roi.z);
+                u0 = fma_h_lo(qb.x, rinv.x, roi.x); u1 = fma_h_hi(qb.x, rinv.x, roi.x);
+                v0 = fma_h_lo(qb.y, rinv.y, roi.y); v1 = fma_h_hi(qb.y, rinv.y, roi.y);
+                w0 = fma_h_lo(qb.z, rinv.z, roi.z); w1 = fma_h_hi(qb.z, rinv.z, roi.z);
+            } else {
             const BvhNode* np = sc.nodes + node;
             const float4 a = np->a, b = np->b, c = np->c;
-            const int4 ch = np->d;
-            float x0, x1, y0, y1, z0, z1, u0, u1, v0, v1, w0, w1;
-            if (FMA_SLAB) {        // t = p * (1/d) - o/d, one full-rate fma per plane: the render kernel's form (NODE_FMT 0)
+            ch = make_int2(np->d.x, np->d.y);
+            if (FMT == 2) {        // t = p * (1/d) - o/d, one full-rate fma per plane: the render kernel's form (NODE_FMT 0)
                 x0 = __builtin_fmaf(a.x, rinv.x, roi.x); x1 = __builtin_fmaf(a.w, rinv.x, roi.x);
                 y0 = __builtin_fmaf(a.y, rinv.y, roi.y); y1 = __builtin_fmaf(b.x, rinv.y, roi.y);
                 z0 = __builtin_fmaf(a.z, rinv.z, roi.z); z1 = __builtin_fmaf(b.y, rinv.z, roi.z);
@@ -844,6 +910,7 @@ k_trace_stream(const DeviceScene sc, uint32_t stack_entries, const float4* __res
                 u0 = (b.z - ro.x) * rinv.x; u1 = (c.y - ro.x) * rinv.x;
                 v0 = (b.w - ro.y) * rinv.y; v1 = (c.z - ro.y) * rinv.y;
                 w0 = (c.x - ro.z) * rinv.z; w1 = (c.w - ro.z) * rinv.z;
+            }
             }
             float n0 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), rtmin));
             float f0 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1)) * kFarWiden;
@@ -1000,27 +1067,36 @@ k_trace_stream_w4(const DeviceScene sc, uint32_t stack_entries, const float4* __
     }
 }
 
-// fmt 0: two-child fp32 tree (stack_entries dwords per lane); fmt 1: four-wide tree (stack_entries 8-byte groups)
+// fmt 0: two-child fp32 tree (stack_entries dwords per lane); fmt 1: four-wide tree (stack_entries 8-byte groups);
+// fmt 2: two-child fp32 tree, fma slab test; fmt 3: two-child fp16 nodes
+typedef void (*StreamKernel)(const DeviceScene, uint32_t, const float4*, uint32_t, uint32_t*, float*, uint32_t*, unsigned long long*);
+static StreamKernel stream_kernel(int fmt)
+{
+    switch (fmt) {
+        case 1: return k_trace_stream_w4<8, 8>;
+        case 2: return k_trace_stream<8, 8, 2>;
+        case 3: return k_trace_stream<8, 8, 3>;
+        default: return k_trace_stream<8, 8, 0>;
+    }
+}
 hipError_t launch_trace_stream(int fmt, const DeviceScene& sc, uint32_t stack_entries, const float* d_rays, uint32_t n, uint32_t* d_head,
                                float* d_t, uint32_t* d_prim, unsigned long long* d_counters, uint32_t grid_blocks, hipStream_t stream)
 {
     const size_t lds = (size_t)(fmt == 1 ? 8 : 4) * stack_entries * 256u;
-    const void* k = fmt == 1 ? (const void*)k_trace_stream_w4<8, 8> : (fmt == 2 ? (const void*)k_trace_stream<8, 8, true> : (const void*)k_trace_stream<8, 8>);
-    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const StreamKernel k = stream_kernel(fmt);
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    if (fmt == 1) k_trace_stream_w4<8, 8><<<grid_blocks, 256, lds, stream>>>(sc, stack_entries, (const float4*)d_rays, n, d_head, d_t, d_prim, d_counters);
-    else if (fmt == 2) k_trace_stream<8, 8, true><<<grid_blocks, 256, lds, stream>>>(sc, stack_entries, (const float4*)d_rays, n, d_head, d_t, d_prim, d_counters);
-    else k_trace_stream<8, 8><<<grid_blocks, 256, lds, stream>>>(sc, stack_entries, (const float4*)d_rays, n, d_head, d_t, d_prim, d_counters);
+    hipLaunchKernelGGL(k, dim3(grid_blocks), dim3(256), lds, stream, sc, stack_entries, (const float4*)d_rays, n, d_head, d_t, d_prim, d_counters);
     return hipGetLastError();
 }
 
 hipError_t trace_stream_occupancy(int fmt, uint32_t stack_entries, int* blocks_per_cu)
 {
     const size_t lds = (size_t)(fmt == 1 ? 8 : 4) * stack_entries * 256u;
-    const void* k = fmt == 1 ? (const void*)k_trace_stream_w4<8, 8> : (fmt == 2 ? (const void*)k_trace_stream<8, 8, true> : (const void*)k_trace_stream<8, 8>);
-    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const StreamKernel k = stream_kernel(fmt);
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k, 256, lds);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, (const void*)k, 256, lds);
 }
 
 // ---- host-side launchers ------------------------------------------------------------------
@@ -1029,41 +1105,57 @@ typedef void (*RenderKernel)(const RenderArgs);
 struct VariantDesc { RenderKernel k; int threads; int node_fmt; const char* name; };
 
 // Render kernel variants.  0: segment-synchronous (fp32 nodes).  Others: persistent traversal
-// <SHADE_K, LEAF_K, NODE_FMT, THREADS>.
+// <SHADE_K, LEAF_K, NODE_FMT, THREADS, MINW, STATS, DIAG, INNER, LEAVES>.  The product library carries the variants a user
+// can meaningfully pick (indices fixed: render_megakernel.h); everything that was measured on the way and lost is
+// compiled only with -DACGPT_EXPERIMENTS (acgpathtracing_amd/_build.py build_hip(experiments=True), tools/sweep_variants.py).
 static const VariantDesc kVariants[] = {
     {k_render, 256, 0, "sync fp32-nodes"},
-    {k_render_pw<44, 16, 0, 256, 4, false, 0, 2, 2>, 256, 0, "pw K44 L16 fp32 w4, register stack top, two visits and two triangle tests per loop trip (default)"},
-    {k_render_pw<44, 16, 0, 256, 4, true, 0, 2, 2>, 256, 0, "default + scheduler stats"},
+    {k_render_pw<44, 16, 0, 256, 4, false, 0, 2, 2>, 256, 0, "pw K44 L16 fp32 nodes w4, register stack top, two visits and two triangle tests per loop trip"},
+    {k_render_pw<44, 16, 0, 256, 4, true, 0, 2, 2>, 256, 0, "pw K44 L16 fp32 nodes + scheduler stats"},
+    {k_render_pw<48, 8, 0, 256, 4, false, 0, 2>, 256, 0, "pw K48 L8 fp32 nodes w4, two visits per loop trip (large scenes whose fp16 planes would be too coarse)"},
+    {k_render_pw<48, 12, 0, 256, 4, false, 3, 1>, 256, 0, "FAST-MATH hardware sin/cos + algebraic acos in the cosine-weighted sampler (opt-in; other bits than the default)"},
+    {k_render_pw<44, 16, 8, 256, 4, false, 0, 3, 2>, 256, 8, "pw K44 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes, w4, three visits and two triangle tests per loop trip"},
+    {k_render_pw<44, 16, 8, 256, 4, true, 0, 3, 2>, 256, 8, "pw K44 L16 fp16 sign-rotated nodes + scheduler stats"},
+#ifdef ACGPT_EXPERIMENTS
     {k_render_pw<40, 8, 0, 256, 4, false, 0, 1>, 256, 0, "pw K40 L8 fp32 w4, register stack top"},
     {k_render_pw<48, 8, 0, 256, 4, false>, 256, 0, "pw K48 L8 fp32 w4, LDS-only stack"},
     {k_render_pw<48, 8, 0, 256, 5, false, 0, 1>, 256, 0, "pw K48 L8 fp32 w5 (register-capped, spills)"},
+    {k_render_pw<44, 16, 7, 256, 4, false, 0, 2, 2>, 256, 7, "pw K44 L16 fp16 nodes, per-axis min / max, V2 T2"},
+    {k_render_pw<48, 8, 7, 256, 4, false, 0, 2>, 256, 7, "pw K48 L8 fp16 nodes, per-axis min / max, V2"},
     {k_render_pw<48, 8, 1, 256, 4, false, 0, 1>, 256, 1, "pw K48 L8 q16 nodes w4"},
     {k_render_pw<48, 8, 2, 1024, 4, false, 0, 1>, 1024, 2, "pw K48 L8 q16 nodes in LDS, 1024 threads"},
     {k_render_pw<48, 8, 0, 256, 4, false, 1, 1>, 256, 0, "DIAG +12 VALU per inner step"},
     {k_render_pw<48, 8, 0, 256, 4, false, 2, 1>, 256, 0, "DIAG +2 loads per inner step"},
-    {k_render_pw<48, 12, 0, 256, 4, false, 3, 1>, 256, 0, "FAST-MATH hardware sin/cos + algebraic acos in the cosine-weighted sampler (opt-in; other bits than the default)"},
     {k_render_pw<48, 8, 3, 256, 4, false, 0, 1>, 256, 3, "pw K48 L8 four-wide 8-bit nodes w4"},
     {k_render_pw<48, 8, 3, 256, 4, true, 0, 1>, 256, 3, "four-wide + scheduler stats"},
-    {k_render_pw<48, 16, 3, 256, 4, false, 0, 1>, 256, 3, "pw K48 L16 four-wide"},
-    {k_render_pw<40, 8, 3, 256, 4, false, 0, 1>, 256, 3, "pw K40 L8 four-wide"},
-    {k_render_pw<48, 8, 3, 256, 5, false, 0, 1>, 256, 3, "pw K48 L8 four-wide w5"},
-    {k_render_pw<48, 8, 0, 256, 4, false, 0, 2>, 256, 0, "pw K48 L8 fp32 w4, two visits per loop trip (kLargeSceneVariant: chosen automatically above 100 k triangles)"},
-    {k_render_pw<48, 16, 0, 256, 4, false, 0, 1>, 256, 0, "pw K48 L16 fp32 w4"},
-    {k_render_pw<44, 12, 0, 256, 4, false, 0, 1>, 256, 0, "pw K44 L12 fp32 w4"},
-    {k_render_pw<48, 12, 0, 256, 4, false, 0, 1>, 256, 0, "pw K48 L12 fp32 w4, one visit per loop trip (default until the two-visit loop)"},
+    {k_render_pw<44, 16, 3, 256, 4, false, 0, 2, 2>, 256, 3, "pw K44 L16 T2 four-wide 8-bit nodes"},
+    {k_render_pw<48, 12, 0, 256, 4, false, 0, 1>, 256, 0, "pw K48 L12 fp32 w4, one visit per loop trip"},
     {k_render_pw<48, 12, 0, 256, 4, false, 0, 3>, 256, 0, "pw K48 L12 fp32 w4, three visits per loop trip"},
-    {k_render_pw<40, 12, 0, 256, 4, false, 0, 2>, 256, 0, "pw K40 L12 fp32 w4, two visits per loop trip"},
     {k_render_pw<44, 12, 0, 256, 4, false, 0, 2, 2>, 256, 0, "pw K44 L12 fp32 w4, two visits and two triangle tests per loop trip"},
-    {k_render_pw<44, 12, 0, 256, 4, false, 0, 2>, 256, 0, "pw K44 L12 fp32 w4, two visits, one triangle test per loop trip (default until the two-test round)"},
-    {k_render_pw<48, 8, 0, 256, 4, false, 0, 2, 2>, 256, 0, "pw K48 L8 V2 T2"},
-    {k_render_pw<48, 12, 0, 256, 4, false, 0, 2, 2>, 256, 0, "pw K48 L12 V2 T2"},
     {k_render_pw<44, 16, 0, 256, 4, false, 0, 2, 3>, 256, 0, "pw K44 L16 V2 T3"},
     {k_render_pw<44, 16, 6, 256, 4, false, 0, 2, 2>, 256, 0, "pw K44 L16 V2 T2 centre / half-extent nodes"},
     {k_render_pw<44, 16, 4, 256, 4, false, 0, 2, 2>, 256, 4, "pw K44 L16 V2 T2 q16 nodes, fma decode"},
-    {k_render_pw<44, 16, 3, 256, 4, false, 0, 2, 2>, 256, 3, "pw K44 L16 T2 four-wide 8-bit nodes"},
-    {k_render_pw<48, 12, 4, 256, 4, false, 0, 1>, 256, 4, "pw K48 L12 q16 nodes, fma decode w4"},
-    {k_render_pw<48, 12, 5, 256, 4, false, 0, 1>, 256, 0, "pw K48 L12 fp32 w4, two-step slab test (p - o) * (1/d) (default until the fma form)"},
-    {k_render_pw<48, 12, 1, 256, 4, false, 0, 1>, 256, 1, "pw K48 L12 q16 nodes w4"},
+    {k_render_pw<48, 12, 5, 256, 4, false, 0, 1>, 256, 0, "pw K48 L12 fp32 w4, two-step slab test (p - o) * (1/d)"},
+    {k_render_pw<44, 16, 8, 256, 4, false, 0, 2, 2>, 256, 8, "pw K44 L16 fp16 nodes, sign-rotated planes (no per-axis min / max) V2 T2"},
+    {k_render_pw<48, 8, 8, 256, 4, false, 0, 2>, 256, 8, "pw K48 L8 fp16 nodes, sign-rotated planes V2"},
+    {k_render_pw<48, 16, 8, 256, 4, false, 0, 2, 2>, 256, 8, "pw K48 L16 fp16 sign-rotated V2 T2"},
+    {k_render_pw<40, 16, 8, 256, 4, false, 0, 2, 2>, 256, 8, "pw K40 L16 fp16 sign-rotated V2 T2"},
+    {k_render_pw<44, 16, 8, 256, 5, false, 0, 3, 2>, 256, 8, "pw K44 L16 fp16 sign-rotated V3 T2 w5"},
+    {k_render_pw<44, 16, 8, 256, 5, false, 0, 2, 2>, 256, 8, "pw K44 L16 fp16 sign-rotated V2 T2 w5"},
+    {k_render_pw<44, 16, 8, 256, 4, false, 0, 4, 2>, 256, 8, "pw K44 L16 fp16 sign-rotated V4 T2"},
+    {k_render_pw<44, 16, 8, 256, 4, false, 0, 3, 3>, 256, 8, "pw K44 L16 fp16 sign-rotated V3 T3"},
+    {k_render_pw<44, 12, 8, 256, 4, false, 0, 3, 2>, 256, 8, "pw K44 L12 fp16 sign-rotated V3 T2"},
+    {k_render_pw<44, 20, 8, 256, 4, false, 0, 3, 2>, 256, 8, "pw K44 L20 fp16 sign-rotated V3 T2"},
+    {k_render_pw<40, 16, 8, 256, 4, false, 0, 3, 2>, 256, 8, "pw K40 L16 fp16 sign-rotated V3 T2"},
+    {k_render_pw<48, 16, 8, 256, 4, false, 0, 3, 2>, 256, 8, "pw K48 L16 fp16 sign-rotated V3 T2"},
+    {k_render_pw<48, 8, 8, 256, 4, false, 0, 3>, 256, 8, "pw K48 L8 fp16 sign-rotated V3 T1"},
+    {k_render_pw<40, 16, 7, 256, 4, false, 0, 2, 2>, 256, 7, "pw K40 L16 fp16 V2 T2"},
+    {k_render_pw<48, 16, 7, 256, 4, false, 0, 2, 2>, 256, 7, "pw K48 L16 fp16 V2 T2"},
+    {k_render_pw<44, 12, 7, 256, 4, false, 0, 2, 2>, 256, 7, "pw K44 L12 fp16 V2 T2"},
+    {k_render_pw<44, 24, 7, 256, 4, false, 0, 2, 2>, 256, 7, "pw K44 L24 fp16 V2 T2"},
+    {k_render_pw<44, 16, 7, 256, 4, false, 0, 3, 2>, 256, 7, "pw K44 L16 fp16 V3 T2"},
+    {k_render_pw<44, 16, 7, 256, 5, false, 0, 2, 2>, 256, 7, "pw K44 L16 fp16 V2 T2 w5"},
+#endif
 };
 int render_variant_count() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
 const char* render_variant_name(int v) { return (v >= 0 && v < render_variant_count()) ? kVariants[v].name : "?"; }

@@ -119,6 +119,8 @@ typedef struct pt_bvh_info {
     uint32_t wide_depth;      /* four-wide tree: levels                       */
     uint32_t wide_bytes;      /* four-wide tree: record array (nodes + triangles, 48 B each) */
     float    wide_ms;         /* collapse of the two-child tree, host ms      */
+    uint32_t half_node_bytes; /* bytes of the fp16 node array (32 B per node)  */
+    float    half_area_ratio; /* summed child-box area with fp16 planes / with fp32 planes (>= 1) */
 } pt_bvh_info;
 
 /* ---- lifetime -------------------------------------------------------------
@@ -190,8 +192,9 @@ int pt_resolve_framebuffer(pt_ctx* ctx, const float* accumulation_rgba, uint8_t*
 int pt_set_sample_chunks(pt_ctx* ctx, int chunks);
 
 /* Launch tuning: persistent workgroups per CU (0 = from the occupancy query) and the render
- * kernel variant (0 = segment-synchronous, n >= 1 = persistent traversal with deferred shading,
- * see csrc/render_megakernel.hip).  Every variant produces the same image bits.           */
+ * kernel variant: -1 = chosen per scene (the default: fp16 nodes where their coarser planes cost < 5 % of
+ * summed child-box area, fp32 nodes otherwise), 0 = segment-synchronous, n >= 1 = persistent traversal
+ * with deferred shading, see csrc/render_megakernel.hip.  Every variant produces the same image bits.   */
 int pt_set_tuning(pt_ctx* ctx, int blocks_per_cu, int variant);
 /* Human-readable description of a kernel variant, NULL past the last one.  Names starting with "DIAG"
  * are timing experiments (some deliberately compute different bits) and are never selected by default. */

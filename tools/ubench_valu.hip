@@ -47,6 +47,14 @@ __global__ void __launch_bounds__(256) NAME(int iters, float* out) { \
 BODY(k_add, A_ADD) BODY(k_mul, A_MUL) BODY(k_fma, A_FMA) BODY(k_max, A_MAX) BODY(k_max3, A_MAX3) BODY(k_and, A_AND)
 BODY(k_addu, A_ADDU) BODY(k_shl, A_SHL) BODY(k_minu, A_MINU) BODY(k_cvtb, A_CVTB) BODY(k_cvtu, A_CVTU) BODY(k_cnd, A_CND)
 BODY(k_bfi, A_BFI) BODY(k_min3, A_MIN3) BODY(k_sub, A_SUB) BODY(k_xor, A_XOR) BODY(k_mad24, A_MAD24)
+#define A_FMAMIX(n) "v_fma_mix_f32 %" #n ", %" #n ", %8, %9 op_sel_hi:[1,0,0]\n"
+#define A_FMAMIXH(n) "v_fma_mix_f32 %" #n ", %" #n ", %8, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+#define A_CVTH(n)  "v_cvt_f32_f16 %" #n ", %" #n "\n"
+#define A_ALIGNBIT(n) "v_alignbit_b32 %" #n ", %" #n ", %" #n ", %10\n"
+#define A_PERM(n) "v_perm_b32 %" #n ", %" #n ", %" #n ", %10\n"
+#define A_MED3(n) "v_med3_f32 %" #n ", %" #n ", %8, %9\n"
+BODY(k_alignbit, A_ALIGNBIT) BODY(k_perm, A_PERM) BODY(k_med3, A_MED3)
+BODY(k_fmamix, A_FMAMIX) BODY(k_fmamixh, A_FMAMIXH) BODY(k_cvth, A_CVTH)
 BODY(k_cmp, A_CMP) BODY(k_rcp, A_RCP) BODY(k_mov, A_MOV) BODY(k_lshlor, A_LSHLOR) BODY(k_andor, A_ANDOR)
 
 __global__ void __launch_bounds__(256) k_cmps(int iters, float* out) {
@@ -221,7 +229,7 @@ int main()
     printf("device %s, %d CUs, %.2f GHz\n", prop.gcnArchName, cus, ghz);
     float* d; CK(hipMalloc(&d, 4));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const Desc ks[] = {{"v_add_f32", k_add}, {"v_mul_f32", k_mul}, {"v_fma_f32", k_fma}, {"v_max_f32", k_max}, {"v_max3_f32", k_max3},
+    const Desc ks[] = {{"v_add_f32", k_add}, {"v_mul_f32", k_mul}, {"v_fma_f32", k_fma}, {"v_fma_mix_f32 (f16 lo src0)", k_fmamix}, {"v_fma_mix_f32 (f16 hi src0)", k_fmamixh}, {"v_cvt_f32_f16", k_cvth}, {"v_alignbit_b32 (vgpr shift)", k_alignbit}, {"v_perm_b32 (vgpr selector)", k_perm}, {"v_med3_f32", k_med3}, {"v_max_f32", k_max}, {"v_max3_f32", k_max3},
                        {"v_and_b32", k_and}, {"v_add_u32", k_addu}, {"v_lshlrev_b32", k_shl}, {"v_min_u32", k_minu}, {"v_cvt_f32_ubyte1", k_cvtb},
                        {"v_cvt_f32_u32", k_cvtu}, {"v_cndmask_b32 (vcc)", k_cnd}, {"v_cmp_lt_f32 vcc", k_cmp}, {"v_cmp_lt_f32 sgpr pair", k_cmps},
                        {"v_cndmask (sgpr pair, set)", k_cnd_s}, {"v_cndmask (vcc from v_cmp)", k_cnd_init}, {"v_cmp + v_cndmask PAIR", k_cmp_cnd},
