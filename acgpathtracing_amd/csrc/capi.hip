@@ -3,6 +3,7 @@
 // CPU path in this library: every entry point fails if no HIP device is usable.
 #include <hip/hip_runtime.h>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -26,7 +27,7 @@ struct pt_ctx {
     int n_cus = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // bracket the render kernel alone (k_items / k_finalize sit outside)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // bracket the render kernel alone (k_finalize sits outside)
     ptd::LbvhResult bvh;
     pt_material* d_mats = nullptr;
     uint32_t n_mats = 0;
@@ -40,8 +41,9 @@ struct pt_ctx {
     unsigned long long* d_counters = nullptr; // 8 counters
     int rank = 0, world = 1;
     int chunks = 0;                           // sample chunks per pixel: 0 = automatic, else 1/2/4/8/16
-    float4* d_partial = nullptr; size_t partial_bytes = 0;
-    uint2* d_items = nullptr; size_t items_bytes = 0;
+    float4* d_frame_sums = nullptr; size_t frame_sums_bytes = 0;   // [pixel][sub-frame] of a frame batch
+    float4* d_wave_scratch = nullptr; size_t wave_scratch_bytes = 0;   // fold slots of every wave of the grid
+    size_t scratch_limit = (size_t)1 << 30;                          // a frame batch is cut into launches whose frame sums fit
     pt_stats stats;
     uint64_t scene_serial = 0;
     std::string err;
@@ -109,8 +111,8 @@ PT_API void pt_destroy(pt_ctx* c)
     free_scene(c);
     if (c->d_queue) (void)hipFree(c->d_queue);
     if (c->d_counters) (void)hipFree(c->d_counters);
-    if (c->d_partial) (void)hipFree(c->d_partial);
-    if (c->d_items) (void)hipFree(c->d_items);
+    if (c->d_frame_sums) (void)hipFree(c->d_frame_sums);
+    if (c->d_wave_scratch) (void)hipFree(c->d_wave_scratch);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -270,12 +272,63 @@ static uint32_t num_samples(int world, uint32_t w, uint32_t h)
     return rows * cols * 32u;
 }
 
+// Granlund & Montgomery division by an invariant (N = 32): exact for every 32-bit numerator
+static ptd::FastDiv make_fast_div(uint32_t d)
+{
+    uint32_t l = 0;
+    while (((uint64_t)1 << l) < d) l++;
+    ptd::FastDiv f;
+    f.mul = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << l) - d)) / d + 1u);
+    f.sh1 = l < 1u ? l : 1u;
+    f.sh2 = l < 1u ? 0u : l - 1u;
+    return f;
+}
+static bool check_fast_div(const ptd::FastDiv& f, uint32_t d, uint32_t n_max)
+{
+    auto q = [&](uint32_t n) { const uint32_t t = (uint32_t)(((uint64_t)n * f.mul) >> 32); return (t + ((n - t) >> f.sh1)) >> f.sh2; };
+    for (uint64_t m = 0; m <= (uint64_t)n_max + d; m += d)           // every multiple of d and its neighbours
+        for (int k = -1; k <= 1; k++) {
+            const uint64_t n = m + (uint64_t)(int64_t)k;
+            if (n <= 0xFFFFFFFFull && (m != 0 || k >= 0) && q((uint32_t)n) != (uint32_t)(n / d)) return false;
+        }
+    return q(0xFFFFFFFFu) == 0xFFFFFFFFu / d;
+}
+
 PT_API int pt_launch(pt_ctx* c, const pt_params* p) { return pt_launch_frames(c, p, 1u); }
+
+static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames);
 
 PT_API int pt_launch_frames(pt_ctx* c, const pt_params* p, uint32_t n_frames)
 {
     if (!c || !p) return fail(c, "pt_launch: null argument");
     if (n_frames < 1u || n_frames > 64u) return fail(c, "pt_launch_frames: n_frames must be in [1, 64]");
+    // one kernel launch holds one float4 per (pixel, sub-frame) until k_finalize has blended them: batches whose sums
+    // would exceed the scratch limit (1 GiB: 32 sub-frames at 1920x1080) run as several launches, same bits
+    const size_t per_frame = (size_t)p->width * p->height * sizeof(float4);
+    uint32_t per_launch = per_frame ? (uint32_t)(c->scratch_limit / per_frame) : n_frames;
+    if (per_launch < 1u) per_launch = 1u;
+    if (per_launch >= n_frames) return launch_batch(c, p, n_frames);
+    pt_params q = *p;
+    pt_stats total;
+    memset(&total, 0, sizeof(total));
+    for (uint32_t done = 0; done < n_frames;) {
+        const uint32_t n = n_frames - done < per_launch ? n_frames - done : per_launch;
+        q.currentFrameIdx = p->currentFrameIdx + done;
+        if (int rc = launch_batch(c, &q, n)) return rc;
+        const pt_stats& s = c->stats;
+        total.radiance_rays += s.radiance_rays; total.shadow_rays += s.shadow_rays; total.paths += s.paths;
+        total.kernel_ms += s.kernel_ms; total.launch_ms += s.launch_ms;
+        total.trav_wave_steps += s.trav_wave_steps; total.trav_lane_steps += s.trav_lane_steps;
+        total.shade_wave_rounds += s.shade_wave_rounds; total.shade_lane_rounds += s.shade_lane_rounds;
+        total.pixels = s.pixels; total.grid_blocks = s.grid_blocks; total.sample_chunks = s.sample_chunks; total.variant = s.variant;
+        done += n;
+    }
+    c->stats = total;
+    return 0;
+}
+
+static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
+{
     const auto t0 = std::chrono::steady_clock::now();
     if (p->width == 0 || p->height == 0) return fail(c, "pt_launch: empty image");
     if (p->width > 65535u || p->height > 65535u) return fail(c, "pt_launch: width and height are limited to 65535 (work items pack them into 16 bits each)");
@@ -293,6 +346,11 @@ PT_API int pt_launch_frames(pt_ctx* c, const pt_params* p, uint32_t n_frames)
     a.width = p->width; a.height = p->height; a.spp = p->samplesPerPixel; a.maxDepth = p->maxDepth; a.frame = p->currentFrameIdx;
     a.eye = p->cameraEye; a.U = p->cameraU; a.V = p->cameraV; a.W = p->cameraW;
     a.light = p->areaLight;
+    {   // :1021 length(cross(v1, v2)) with the operations of sutil/vec_math.h:533-542 (this file is built with -ffp-contract=off)
+        const pt_float3 u = p->areaLight.v1, v = p->areaLight.v2;
+        const float cx = u.y * v.z - u.z * v.y, cy = u.z * v.x - u.x * v.z, cz = u.x * v.y - u.y * v.x;
+        a.light_area = sqrtf(cx * cx + cy * cy + cz * cz);
+    }
     a.useDL = p->useDirectLighting ? 1u : 0u;
     a.useIS = p->useImportanceSampling ? 1u : 0u;
     a.rank = c->rank; a.world = c->world;
@@ -325,26 +383,29 @@ PT_API int pt_launch_frames(pt_ctx* c, const pt_params* p, uint32_t n_frames)
     if (((uint64_t)num_samples(c->world, p->width, p->height) << a.sub_shift) >= 0x7FFFFFFFull)
         return fail(c, "pt_launch: image too large for this sample-chunk count and frame batch (2^31 work items)");
     a.total_samples = num_samples(c->world, p->width, p->height) << a.sub_shift;
+    a.strip_cols = p->width / (8u * (uint32_t)c->world) + (p->width % (8u * (uint32_t)c->world) == 0 ? 0u : 1u);
+    a.div_cols = make_fast_div(a.strip_cols);
+    a.div_world = make_fast_div((uint32_t)c->world);
+    if (!check_fast_div(a.div_cols, a.strip_cols, num_samples(c->world, p->width, p->height) / 32u) ||
+        !check_fast_div(a.div_world, (uint32_t)c->world, 65536u + (uint32_t)c->world))
+        return fail(c, "pt_launch: internal error (division constants)");
     a.shard_size = ((a.total_samples + 7u) / 8u + 63u) & ~63u;
-    {
-        const size_t need = (size_t)a.total_samples * sizeof(uint2);
-        if (need > c->items_bytes) {
+    if (n_frames > 1u) {
+        const size_t need = (size_t)p->width * p->height * n_frames * sizeof(float4);
+        if (need > c->frame_sums_bytes) {
             CK(c, hipStreamSynchronize(c->stream));
-            if (c->d_items) { (void)hipFree(c->d_items); c->d_items = nullptr; c->items_bytes = 0; }
-            CK(c, hipMalloc((void**)&c->d_items, need));
-            c->items_bytes = need;
+            if (c->d_frame_sums) { (void)hipFree(c->d_frame_sums); c->d_frame_sums = nullptr; c->frame_sums_bytes = 0; }
+            CK(c, hipMalloc((void**)&c->d_frame_sums, need));
+            c->frame_sums_bytes = need;
         }
-        a.items = c->d_items;
+        a.frame_sums = c->d_frame_sums;
     }
-    if (a.sub_shift) {
-        const size_t need = ((size_t)p->width * p->height << a.sub_shift) * sizeof(float4);
-        if (need > c->partial_bytes) {
-            CK(c, hipStreamSynchronize(c->stream));
-            if (c->d_partial) { (void)hipFree(c->d_partial); c->d_partial = nullptr; c->partial_bytes = 0; }
-            CK(c, hipMalloc((void**)&c->d_partial, need));
-            c->partial_bytes = need;
-        }
-        a.partial = c->d_partial;
+    {   // scene box for the camera-ray cull, enlarged by 2^-10 of its extent (+ a floor) beyond the roundings of reaches_scene()
+        float ext = 0.0f;
+        for (int k = 0; k < 3; k++) ext = fmaxf(ext, c->bvh.scene_hi[k] - c->bvh.scene_lo[k]);
+        const float grow = ext * (1.0f / 1024.0f) + 1e-6f;
+        a.cull_lo = {c->bvh.scene_lo[0] - grow, c->bvh.scene_lo[1] - grow, c->bvh.scene_lo[2] - grow};
+        a.cull_hi = {c->bvh.scene_hi[0] + grow, c->bvh.scene_hi[1] + grow, c->bvh.scene_hi[2] + grow};
     }
     a.queue_heads = c->d_queue;
     a.counters = c->d_counters;
@@ -364,13 +425,22 @@ PT_API int pt_launch_frames(pt_ctx* c, const pt_params* p, uint32_t n_frames)
     if (grid > blocks_needed) grid = blocks_needed;
     if (grid < 1) grid = 1;
 
+    if (a.chunk_shift) {   // fold slots for every wave of the grid
+        const size_t need = (size_t)grid * wpb * ((size_t)ptd::kRenderFoldSlots << a.chunk_shift) * sizeof(float4);
+        if (need > c->wave_scratch_bytes) {
+            CK(c, hipStreamSynchronize(c->stream));
+            if (c->d_wave_scratch) { (void)hipFree(c->d_wave_scratch); c->d_wave_scratch = nullptr; c->wave_scratch_bytes = 0; }
+            CK(c, hipMalloc((void**)&c->d_wave_scratch, need));
+            c->wave_scratch_bytes = need;
+        }
+        a.wave_scratch = c->d_wave_scratch;
+    }
     CK(c, hipMemsetAsync(c->d_queue, 0, 8 * sizeof(uint32_t), c->stream));
     CK(c, hipMemsetAsync(c->d_counters, 0, (8 + 3 * (size_t)ptd::kMaxTimedWaves + 2049) * sizeof(unsigned long long), c->stream));
-    CK(c, ptd::launch_items(a, c->stream));
     CK(c, hipEventRecord(c->ev0, c->stream));
     CK(c, ptd::launch_render(c->variant, a, grid, c->stream));
     CK(c, hipEventRecord(c->ev1, c->stream));
-    if (a.sub_shift) CK(c, ptd::launch_finalize(a, c->stream));
+    if (n_frames > 1u) CK(c, ptd::launch_finalize(a, c->stream));
     unsigned long long h[8];
     CK(c, hipMemcpyAsync(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     CK(c, hipStreamSynchronize(c->stream));            // CUDA_SYNC_CHECK, PathTracerMain.cpp:209

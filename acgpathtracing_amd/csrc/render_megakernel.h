@@ -6,6 +6,7 @@
 namespace ptd {
 
 constexpr int kRenderThreads = 256;   // 4 waves per workgroup (segment-synchronous variant)
+constexpr uint32_t kRenderFoldSlots = 128;  // fold slots per wave (render_megakernel.hip kFoldSlots)
 constexpr uint32_t kMaxTimedWaves = 16384;   // stats variants stamp start / queue-empty / end per wave behind the 8 counters
 // Variant indices of the product library (render_megakernel.hip kVariants).  pt_set_scene picks one per scene unless
 // pt_set_tuning named one: fp16 nodes when the fp16 planes cost less than kHalfAreaLimit in summed child-box area (every
@@ -16,6 +17,8 @@ constexpr int kDefaultVariant = kVariantF16;
 constexpr uint32_t kLargeSceneTris = 100000;
 constexpr float kHalfAreaLimit = 1.05f;
 
+struct FastDiv { uint32_t mul, sh1, sh2; };     // n / d = (t + ((n - t) >> sh1)) >> sh2, t = mulhi(n, mul)  (render_megakernel.hip fast_div)
+
 struct RenderArgs {
     DeviceScene scene;
     float4*   accum;        // PathTraceParams::accumulationBuffer
@@ -23,6 +26,7 @@ struct RenderArgs {
     uint32_t  width, height, spp, maxDepth, frame;
     pt_float3 eye, U, V, W;
     pt_area_light light;
+    float     light_area;      // |light.v1 x light.v2| (:1021), fp32, evaluated on the host
     uint32_t  useDL, useIS;
     int       rank, world;
     uint32_t  total_samples;   // queue length: StaticWorkDistribution::numSamples(world) << sub_shift
@@ -43,9 +47,12 @@ struct RenderArgs {
     uint32_t  sub_shift;       // ceil_log2(n_frames) + chunk_shift
     uint32_t  lcg_mul[32];     // seed of chunk k = lcg_mul[k] * seed0 + lcg_add[k]  (2 * k * chunk_spp LCG steps)
     uint32_t  lcg_add[32];
-    float4*   partial;         // [pixel][sub] partial sums, used when sub_shift > 0
+    float4*   frame_sums;      // [pixel][n_frames] sums of the sub-frames of a batch (n_frames > 1): k_finalize blends them in order
+    float4*   wave_scratch;    // [wave of the grid][kFoldSlots << chunk_shift] partial sums of runs whose group is still open (chunk_shift > 0)
     uint32_t  grant;           // minimum work items taken per queue atomic (1 = exactly what is needed)
-    uint2*    items;           // [total_samples] work items of this launch: {px | py << 16, seed} (k_items)
+    uint32_t  strip_cols;      // tile-strip columns of StaticWorkDistribution for (width, world)
+    FastDiv   div_cols, div_world;
+    pt_float3 cull_lo, cull_hi;   // scene bounding box, enlarged: a camera ray that misses it ends its path without a traversal
 };
 
 int render_variant_count();
@@ -54,7 +61,6 @@ int render_variant_threads(int variant);
 int render_variant_node_format(int variant);   // 0 fp32 two-child, 7 fp16 two-child; experiments: 1/2/4 16-bit grid, 3 four-wide 8-bit
 hipError_t render_occupancy(int variant, uint32_t stack_entries, uint32_t n_nodes, int* blocks_per_cu);
 hipError_t launch_render(int variant, const RenderArgs& args, uint32_t grid_blocks, hipStream_t stream);
-hipError_t launch_items(const RenderArgs& args, hipStream_t stream);
 hipError_t launch_finalize(const RenderArgs& args, hipStream_t stream);
 hipError_t launch_resolve(const float4* accum, uint32_t* fb, uint32_t n, hipStream_t stream);
 hipError_t launch_trace_stream(int fmt, const DeviceScene& sc, uint32_t stack_entries, const float* d_rays, uint32_t n, uint32_t* d_head,

@@ -5,16 +5,19 @@
 // traversal underneath them (:600-613, :660-671).
 //
 // Kernels of one pt_launch, in stream order:
-//   k_items      tabulates the work items (pixel, run of samples) of this launch
 //   k_render_pw  the persistent megakernel (default; k_render = segment-synchronous baseline)
-//   k_finalize   only when a pixel is cut into several runs: adds the runs in order, resolves
+//   k_finalize   only for a batch of several sub-frames: folds the sub-frames into the accumulation buffer in order
 //
 // Scheduling (wave64, persistent):
 //   * the grid is sized to the chip (CUs x resident workgroups), never to the image;
 //   * one lane owns one work item and walks its samples in the reference's order as a FLAT loop;
 //     a lane whose path ends regenerates the next camera path right away, a lane whose item is
 //     finished takes the next one from the queue (ballot of the idle lanes, one atomicAdd by the
-//     first of them, popcount-prefix hand-out, wave-local reserve); 8 queue shards, one per XCD;
+//     first of them, popcount-prefix hand-out, wave-local reserve); 8 queue shards, one per XCD; an item is
+//     decoded from its index alone (tile order -> pixel, tea<4> seed, LCG skip-ahead): no table in memory;
+//   * the runs a pixel's samples are cut into are summed in run order by the wave that was granted them
+//     (fold slots, below): no per-run buffer in memory either;
+//   * a camera ray that misses the scene's bounding box ends its path on the spot;
 //   * radiance and shadow rays share one BVH loop; lanes with a finished ray park until enough of
 //     them are waiting, then that batch is shaded and re-armed (k_render_pw);
 //   * the traversal stack lives in LDS, entry-major (pt_device.h), sized from the measured tree
@@ -30,51 +33,89 @@ namespace ptd {
 extern __shared__ uint32_t lds_dyn[];
 
 // ---- pixel queue ---------------------------------------------------------------------------------
-// Work item = (pixel, sub-frame of the batch, sample chunk).  k_items tabulates every item of this launch
-// once (pixel coordinates from the tile order of sutil/WorkDistribution.h, seed = tea<4>(pixel, frame)
-// skipped ahead to the chunk's first sample), so taking an item inside the render kernel is one 8-byte load.
-// Grants: the first idle lane (ffs of the ballot) takes max(idle lanes, A.grant) consecutive items of the
-// wave's queue shard with ONE atomicAdd; the wave hands them out by popcount-prefix and keeps the rest as a
-// reserve, so most refills touch no atomic at all.  Shards are per XCD; drained shards are stolen
-// from round-robin.
-constexpr uint32_t kNoItem = 0xFFFFFFFFu;
+// Work item = (pixel, sub-frame of the batch, run of samples); index = pixel slot << sub_shift | sub-frame << chunk_shift
+// | run.  The pixel slot is the position in the 8x4-tile order of sutil/WorkDistribution.h for (rank, world); everything
+// a lane needs (pixel coordinates, seed = tea<4>(pixel, frame) skipped ahead to the run's first sample) follows from
+// the index, so taking an item touches no memory.
+// Grants: the first idle lane (ffs of the ballot) takes max(idle lanes, A.grant) consecutive items — rounded up to
+// whole (pixel, sub-frame) groups — of the wave's queue shard with ONE atomicAdd; the wave hands them out by
+// popcount-prefix and keeps the rest as a reserve, so most refills touch no atomic at all.  Shards are per XCD;
+// drained shards are stolen from round-robin.
+//
+// Fold slots: all runs of one (pixel, sub-frame) are granted to ONE wave (grants are whole groups).  A group gets a
+// slot of the wave's scratch when its first run is dealt; a lane that finishes a run parks its partial sum there and
+// bumps the slot's ticket (a wave-local counter: lane s of two registers holds the count of slot s); the lane that
+// brings the ticket to the run count adds the partial sums in run order — the association orc_render(chunks) uses —
+// and writes the pixel.  Open groups per wave <= 64 lanes + 1 partially dealt, slots 128.
+constexpr uint32_t kFoldSlots = 128u;
+constexpr uint32_t kNoSlot = 0xFFu;
 
-__global__ void k_items(const RenderArgs A)
-{
-    const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
-    if (item >= A.total_samples) return;
-    const uint32_t sub = item & ((1u << A.sub_shift) - 1u);
-    const uint32_t chunk = sub & ((1u << A.chunk_shift) - 1u);
-    const uint32_t f = sub >> A.chunk_shift;
-    int x, y;
-    sample_pixel(A.world, (int)A.width, A.rank, (int)(item >> A.sub_shift), x, y);
-    uint2 r = make_uint2(kNoItem, 0u);
-    if ((uint32_t)x < A.width && (uint32_t)y < A.height && f < A.n_frames) {
-        const uint32_t pix = (uint32_t)y * A.width + (uint32_t)x;
-        // :721, then skip the jitter draws of the samples before this chunk (2 per sample)
-        r = make_uint2((uint32_t)x | ((uint32_t)y << 16), A.lcg_mul[chunk] * tea4(pix, A.frame + f) + A.lcg_add[chunk]);
-    }
-    A.items[item] = r;
-}
-
-struct QueueState { uint32_t shard, shards_left, res_first, res_count; };
+struct QueueState {
+    uint32_t shard, shards_left, res_first, res_count;
+    uint32_t cur_slot;                    // slot of the group the reserve currently stands inside (kNoSlot: padding group)
+    uint32_t cur_pxy, cur_seed0;          // that group's pixel and tea<4> seed (valid while cur_slot != kNoSlot)
+    unsigned long long free0, free1;      // free fold slots 0..63, 64..127
+};
 
 struct LanePixel {
     bool alive, new_path;
-    uint32_t pix, px, py, seed, samples_left;
-    uint32_t chunk;      // sub index: which sub-frame of the batch and which run of its samples this lane owns
+    uint32_t pxy;          // px | py << 16
+    uint32_t seed, samples_left;
+    uint32_t tag;          // sub-frame << chunk_shift | run, fold slot << 16
     f3 result;
 };
 
-template <bool STATS = false>
-__device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q, uint32_t lane, unsigned long long below, LanePixel& lp)
+__device__ __forceinline__ uint32_t pixel_index(const RenderArgs& A, const LanePixel& lp) { return (lp.pxy >> 16) * A.width + (lp.pxy & 0xFFFFu); }
+
+__device__ __forceinline__ uint32_t alloc_slot(QueueState& q)
 {
+    if (q.free0 != 0ull) { const uint32_t s = (uint32_t)__ffsll((long long)q.free0) - 1u; q.free0 &= q.free0 - 1ull; return s; }
+    if (q.free1 != 0ull) { const uint32_t s = (uint32_t)__ffsll((long long)q.free1) - 1u; q.free1 &= q.free1 - 1ull; return 64u + s; }
+    return kNoSlot;
+}
+__device__ __forceinline__ void free_slot(QueueState& q, uint32_t s)
+{
+    if (s < 64u) q.free0 |= 1ull << s; else q.free1 |= 1ull << (s - 64u);
+}
+
+// n / d for a launch constant d by multiply-high and shifts (Granlund & Montgomery 1994, N = 32: exact for every
+// 32-bit n); capi.hip builds {mul, sh1, sh2} and checks them.  Integer division has no scalar instruction and costs
+// ~40 vector ones; this is 4, and on wave-uniform operands they are scalar.
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, const FastDiv& d)
+{
+    const uint32_t t = __umulhi(n, d.mul);
+    return (t + ((n - t) >> d.sh1)) >> d.sh2;
+}
+// StaticWorkDistribution::getSamplePixel (sutil/WorkDistribution.h:60-81) with the two divisions by launch constants
+// (tile-strip columns, GPU count) as fast_div; same results as sample_pixel()
+__device__ __forceinline__ void sample_pixel_fast(const RenderArgs& A, uint32_t sample_idx, uint32_t& px, uint32_t& py)
+{
+    const uint32_t world = (uint32_t)A.world;
+    const uint32_t tile_strip_idx = sample_idx >> 5;                       // 8 x 4 pixels per tile
+    const uint32_t tile_strip_y = fast_div(tile_strip_idx, A.div_cols);
+    const uint32_t tile_strip_x = tile_strip_idx - tile_strip_y * A.strip_cols;
+    const uint32_t tile_pixel_idx = sample_idx & 31u;
+    const uint32_t a = (uint32_t)A.rank + (tile_strip_y - fast_div(tile_strip_y, A.div_world) * world);   // gpu_idx + tile_strip_y % num_gpus
+    const uint32_t tile_offset_x = (a - fast_div(a, A.div_world) * world) * 8u;
+    py = tile_strip_y * 4u + (tile_pixel_idx >> 3);
+    px = tile_strip_x * (8u * world) + (tile_pixel_idx & 7u) + tile_offset_x;
+}
+
+// lcg_skip: {multiplier, increment} of the LCG skip-ahead per run, staged in LDS by the kernel (a per-lane table look-up
+// in the kernel-argument segment would be a global load on the deal's critical path)
+template <bool STATS = false>
+__device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q, uint32_t lane, unsigned long long below, LanePixel& lp,
+                                             const uint32_t* lcg_skip)
+{
+    const uint32_t cs = A.chunk_shift, run_mask = (1u << cs) - 1u;
+    const uint32_t fshift = A.sub_shift - cs, fmask = (1u << fshift) - 1u;      // group index = pixel slot << fshift | sub-frame
     unsigned long long idle = vote(!lp.alive);
     while (idle != 0ull && (q.res_count != 0u || q.shards_left != 0u)) {
         if (q.res_count == 0u) {                                      // wave-uniform: fetch a grant
             const uint32_t leader = (uint32_t)__ffsll((long long)idle) - 1u;
             const uint32_t idle_n = (uint32_t)popc(idle);
-            const uint32_t req = idle_n > A.grant ? idle_n : A.grant;   // at least what is needed now
+            uint32_t req = idle_n > A.grant ? idle_n : A.grant;       // at least what is needed now,
+            req = (req + run_mask) & ~run_mask;                       // in whole groups (shards begin on group boundaries)
             uint32_t base = 0;
             if (lane == leader) base = atomicAdd(&A.queue_heads[q.shard], req);
             base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
@@ -95,23 +136,59 @@ __device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q,
             if (avail == 0u) continue;
         }
         const uint32_t want = (uint32_t)popc(idle);
-        const uint32_t take = want < q.res_count ? want : q.res_count;
+        uint32_t take = want < q.res_count ? want : q.res_count;
         const uint32_t rank = (uint32_t)popc(idle & below);
-        if (!lp.alive && rank < take) {
-            const uint32_t item = q.res_first + rank;
-            const uint2 it = A.items[item];
-            if (it.x != kNoItem) {
-                lp.px = it.x & 0xFFFFu; lp.py = it.x >> 16;
-                lp.pix = lp.py * A.width + lp.px;
-                lp.chunk = item & ((1u << A.sub_shift) - 1u);
-                lp.seed = it.y;
+        const uint32_t item = q.res_first + rank;
+        if (cs == 0u) {
+            // one run per (pixel, sub-frame): every lane decodes its own item
+            uint32_t x, y;
+            sample_pixel_fast(A, item >> A.sub_shift, x, y);
+            const uint32_t f = item & fmask;
+            if (!lp.alive && rank < take && x < A.width && y < A.height && f < A.n_frames) {   // else: padding of the tile / batch grid
+                lp.pxy = x | (y << 16);
+                lp.tag = f | (kNoSlot << 16);
+                lp.seed = tea4(y * A.width + x, A.frame + f);                                 // :721
                 lp.result = mk(0.0f);
                 lp.samples_left = A.chunk_spp;
                 lp.alive = true;
                 lp.new_path = true;
             }
+        } else {
+            // Several runs per group.  The deal touches <= take / runs + 1 consecutive groups; each is decoded ONCE, on
+            // wave-uniform values (scalar unit: tile order -> pixel, tea<4> seed), gets its fold slot, and the lanes that
+            // drew one of its runs copy the result and skip the LCG ahead to their run.
+            const uint32_t g_first = q.res_first >> cs, g_last = (q.res_first + take - 1u) >> cs;
+            const uint32_t my_g = item >> cs;
+            const uint32_t run = item & run_mask;
+            for (uint32_t g = g_first; g <= g_last; g++) {
+                const uint32_t f = g & fmask;
+                uint32_t sl, pxy, seed0;
+                if ((g << cs) < q.res_first) {                         // the group the previous deal stopped inside: decoded then
+                    sl = q.cur_slot; pxy = q.cur_pxy; seed0 = q.cur_seed0;
+                } else {
+                    uint32_t x, y;
+                    sample_pixel_fast(A, g >> fshift, x, y);
+                    sl = kNoSlot; pxy = x | (y << 16); seed0 = 0u;
+                    if (x < A.width && y < A.height && f < A.n_frames) {   // else: padding of the tile / batch grid
+                        sl = alloc_slot(q);
+                        if (sl == kNoSlot) { take = (g << cs) - q.res_first; break; }   // cannot happen (see above); deal the rest next round
+                        seed0 = tea4(y * A.width + x, A.frame + f);    // :721
+                    }
+                    q.cur_slot = sl; q.cur_pxy = pxy; q.cur_seed0 = seed0;
+                }
+                if (sl != kNoSlot && !lp.alive && rank < take && my_g == g) {
+                    lp.pxy = pxy;
+                    lp.tag = (f << cs) | run | (sl << 16);
+                    lp.seed = lcg_skip[2u * run] * seed0 + lcg_skip[2u * run + 1u];     // skip the jitter draws of the samples before this run (2 per sample)
+                    lp.result = mk(0.0f);
+                    lp.samples_left = A.chunk_spp;
+                    lp.alive = true;
+                    lp.new_path = true;
+                }
+            }
         }
         q.res_first += take; q.res_count -= take;
+        if (take == 0u) break;
         idle = vote(!lp.alive);          // lanes that drew a padding item try again
     }
 }
@@ -137,115 +214,157 @@ __device__ __forceinline__ void resolve_pixel(const RenderArgs& A, uint32_t pix,
     if (A.fb) A.fb[pix] = make_color(accum);
 }
 
-// a lane has finished its run of samples: either the whole pixel (write it) or one chunk (park the
-// partial sum; k_finalize adds the chunks in chunk order)
-__device__ __forceinline__ void write_pixel(const RenderArgs& A, const LanePixel& lp)
+// the sum of one (pixel, sub-frame) is complete: a single launch step resolves the pixel right away; inside a batch the
+// sum is parked per (pixel, sub-frame) and k_finalize blends the sub-frames in frame order
+__device__ __forceinline__ void write_frame_sum(const RenderArgs& A, uint32_t pix, uint32_t f, const f3& sum)
 {
-    if (A.sub_shift == 0u) resolve_pixel(A, lp.pix, lp.result);
-    else A.partial[((size_t)lp.pix << A.sub_shift) + lp.chunk] = make_float4(lp.result.x, lp.result.y, lp.result.z, 0.0f);
+    if (A.n_frames == 1u) resolve_pixel(A, pix, sum);
+    else A.frame_sums[(size_t)pix * A.n_frames + f] = make_float4(sum.x, sum.y, sum.z, 0.0f);
 }
 
-// chunked / batched launches: for every pixel of this rank and every sub-frame in frame order, sum the partial
-// sums in chunk order and blend the sub-frame in — the arithmetic n_frames separate launches would do.
-// A workgroup owns 256 consecutive pixels of the rank's tile order.  The partial sums of one pixel are
-// 2^sub_shift float4 in a row, one pixel's row far from the next, so a thread reading its own row would touch one
-// 16-byte piece of 64 different lines per load.  Instead the workgroup fetches, per sub-frame, groups of up to 8 chunks
-// for all its pixels with consecutive threads on consecutive addresses (whole 128-byte runs), parks them in LDS, and
-// each thread then adds its pixel's values from there in chunk order.
-constexpr uint32_t kFinThreads = 256, kFinGroup = 8;
+// Lanes with `finished` set have completed their run of samples.  One run per pixel: write.  Several: park the partial
+// sum in the group's fold slot, bump the ticket, and let the lane that completes the group add the runs in order.
+// tick_lo / tick_hi: lane s holds the ticket of slot s / 64 + s.  scratch: this wave's kFoldSlots << chunk_shift float4.
+__device__ __forceinline__ void finish_runs(const RenderArgs& A, QueueState& q, const LanePixel& lp, bool finished, uint32_t lane,
+                                            uint32_t& tick_lo, uint32_t& tick_hi, float4* __restrict__ scratch)
+{
+    const unsigned long long fin = vote(finished);
+    if (fin == 0ull) return;
+    const uint32_t cs = A.chunk_shift, runs = 1u << cs;
+    const uint32_t sub = lp.tag & 0xFFFFu;
+    if (cs == 0u) {
+        if (finished) write_frame_sum(A, pixel_index(A, lp), sub, lp.result);
+        return;
+    }
+    const uint32_t slot = lp.tag >> 16;
+    float4* group = scratch + ((size_t)slot << cs);
+    if (finished) group[sub & (runs - 1u)] = make_float4(lp.result.x, lp.result.y, lp.result.z, 0.0f);
+    unsigned long long folders = 0ull;
+    for (unsigned long long m = fin; m != 0ull; m &= m - 1ull) {          // wave-uniform: one turn per finishing lane
+        const int l = __ffsll((long long)m) - 1;
+        const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)slot, l);
+        const bool hi = sl >= 64u;
+        const int tl = (int)(sl & 63u);
+        uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)(hi ? tick_hi : tick_lo), tl) + 1u;
+        if (c == runs) { folders |= 1ull << l; c = 0u; free_slot(q, sl); }
+        if (hi) tick_hi = (int)lane == tl ? c : tick_hi;
+        else    tick_lo = (int)lane == tl ? c : tick_lo;
+    }
+    if (folders == 0ull) return;
+    // the partial sums were stored by lanes of this wave through this CU's L1: wait for the stores, then read them back
+    // past the L1 (agent-scope loads), whatever lines an earlier use of the slot left there
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0) only
+    if ((folders >> lane) & 1ull) {
+        const uint32_t* g = (const uint32_t*)group;
+        f3 sum = mk(0.0f);
+        for (uint32_t k = 0; k < runs; k++) {
+            const float vx = __uint_as_float(__hip_atomic_load(g + 4u * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const float vy = __uint_as_float(__hip_atomic_load(g + 4u * k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const float vz = __uint_as_float(__hip_atomic_load(g + 4u * k + 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (k == 0u) sum = mk(vx, vy, vz); else sum += mk(vx, vy, vz);      // the chain starts at run 0, not at zero
+        }
+        write_frame_sum(A, pixel_index(A, lp), sub >> cs, sum);
+    }
+}
+
+// frame batches: for every pixel of this rank, blend the sub-frames' sums into the accumulation buffer in frame order —
+// the arithmetic n_frames separate launches would do.  One thread per pixel slot of the rank's tile order.
+constexpr uint32_t kFinThreads = 256;
 __global__ void __launch_bounds__(kFinThreads) k_finalize(const RenderArgs A)
 {
-    __shared__ uint32_t s_pix[kFinThreads];
-    __shared__ float4 s_tile[kFinThreads * (kFinGroup + 1)];          // one float4 of padding per pixel row
-    const uint32_t t = threadIdx.x;
-    const uint32_t slot = blockIdx.x * kFinThreads + t;
-    const uint32_t n_slots = A.total_samples >> A.sub_shift;
-    uint32_t pix = 0xFFFFFFFFu;
-    if (slot < n_slots) {
-        int x, y;
-        sample_pixel(A.world, (int)A.width, A.rank, (int)slot, x, y);
-        if ((uint32_t)x < A.width && (uint32_t)y < A.height) pix = (uint32_t)y * A.width + (uint32_t)x;
-    }
-    s_pix[t] = pix;
-    const uint32_t chunks = 1u << A.chunk_shift;
-    const uint32_t grp = chunks < kFinGroup ? chunks : kFinGroup;     // chunks per staging round (a power of two)
-    const uint32_t grp_shift = A.chunk_shift < 3u ? A.chunk_shift : 3u;
+    const uint32_t slot = blockIdx.x * kFinThreads + threadIdx.x;
+    if (slot >= (A.total_samples >> A.sub_shift)) return;
+    int x, y;
+    sample_pixel(A.world, (int)A.width, A.rank, (int)slot, x, y);
+    if ((uint32_t)x >= A.width || (uint32_t)y >= A.height) return;
+    const uint32_t pix = (uint32_t)y * A.width + (uint32_t)x;
     f3 accum = mk(0.0f);
-    if (pix != 0xFFFFFFFFu && A.frame > 0u) { const float4 q = A.accum[pix]; accum = mk(q.x, q.y, q.z); }
-    __syncthreads();
+    if (A.frame > 0u) { const float4 q = A.accum[pix]; accum = mk(q.x, q.y, q.z); }
+    const float4* row = A.frame_sums + (size_t)pix * A.n_frames;
     for (uint32_t f = 0; f < A.n_frames; f++) {
-        f3 sum = mk(0.0f);
-        for (uint32_t k0 = 0; k0 < chunks; k0 += grp) {
-            // stage: element e = (pixel p of the workgroup, chunk k0 + k), consecutive e on consecutive threads
-            for (uint32_t e = t; e < kFinThreads * grp; e += kFinThreads) {
-                const uint32_t p = e >> grp_shift, k = e & (grp - 1u);
-                const uint32_t pp = s_pix[p];
-                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (pp != 0xFFFFFFFFu) v = A.partial[((size_t)pp << A.sub_shift) + ((size_t)f << A.chunk_shift) + k0 + k];
-                s_tile[p * (kFinGroup + 1) + k] = v;
-            }
-            __syncthreads();
-            if (pix != 0xFFFFFFFFu) {
-                const float4* row = s_tile + t * (kFinGroup + 1);
-                uint32_t k = 0;
-                if (k0 == 0u) { sum = mk(row[0].x, row[0].y, row[0].z); k = 1; }      // the chain starts at chunk 0, not at zero
-                for (; k < grp; k++) sum += mk(row[k].x, row[k].y, row[k].z);
-            }
-            __syncthreads();
-        }
-        accum = blend_frame(accum, sum, A.spp, A.frame + f);
+        const float4 v = row[f];
+        accum = blend_frame(accum, mk(v.x, v.y, v.z), A.spp, A.frame + f);
     }
-    if (pix != 0xFFFFFFFFu) {
-        A.accum[pix] = make_float4(accum.x, accum.y, accum.z, 1.0f);
-        if (A.fb) A.fb[pix] = make_color(accum);
-    }
+    A.accum[pix] = make_float4(accum.x, accum.y, accum.z, 1.0f);
+    if (A.fb) A.fb[pix] = make_color(accum);
 }
 
 __device__ __forceinline__ ShadeConsts shade_consts(const RenderArgs& A)
 {
     ShadeConsts K;
     K.Lc = mk(A.light.corner); K.Lv1 = mk(A.light.v1); K.Lv2 = mk(A.light.v2); K.Ln = mk(A.light.normal); K.Le = mk(A.light.emission);
-    K.lightA = length(cross(K.Lv1, K.Lv2));                         // :1021
+    K.lightA = A.light_area;                                        // :1021 |v1 x v2|, evaluated once on the host with the same fp32 operations
     K.useDL = A.useDL; K.useIS = A.useIS;
     return K;
 }
+
+// Camera ray through pixel (px, py) with jitter (jx, jy), unnormalised (:730-737)
+__device__ __forceinline__ f3 camera_dir(float px, float py, float jx, float jy, float fw, float fh, const f3& U, const f3& V, const f3& W)
+{
+    const float dx = 2.0f * ((px + jx) / fw) - 1.0f;
+    const float dy = 2.0f * ((py + jy) / fh) - 1.0f;
+    return dx * U + dy * V + W;
+}
+// Can a ray from the eye along D (any length) reach the scene's bounding box?  elo / ehi: box corners minus the eye, the box
+// itself enlarged on the host beyond every rounding below.  false = certain miss: no triangle can be hit, the path is the
+// reference's __miss__ms case (:833-847) without a traversal.
+__device__ __forceinline__ bool reaches_scene(const f3& D, const f3& elo, const f3& ehi)
+{
+    const float rx = finite_rcp(D.x), ry = finite_rcp(D.y), rz = finite_rcp(D.z);
+    const float x0 = elo.x * rx, x1 = ehi.x * rx, y0 = elo.y * ry, y1 = ehi.y * ry, z0 = elo.z * rz, z1 = ehi.z * rz;
+    const float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+    const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1)) * kFarWiden;
+    return tn <= tf;
+}
+
+// The launch constants live in the kernel-argument segment.  Left to itself the compiler loads all of them once, keeps
+// them in scalar registers for the whole kernel and, out of registers, spills the BVH loop's own pointers.  The persistent
+// kernel therefore re-reads what only the shade phase needs at the start of every shade round, through an index the
+// compiler cannot see through (a zero made by an opaque instruction), so those values never live across the BVH loop.
+struct RenderArgsBox { RenderArgs a[1]; };
+__device__ __forceinline__ uint32_t opaque_zero() { uint32_t z; asm volatile("s_mov_b32 %0, 0" : "=s"(z)); return z; }
 
 // =================================================================================================
 // Variant 0: segment-synchronous.  Every iteration: all live lanes trace one radiance segment to
 // completion, shade, (some) trace a shadow ray, account.  Simple; lanes wait for the slowest ray.
 // =================================================================================================
 __global__ void __launch_bounds__(kRenderThreads)
-k_render(const RenderArgs A)
+k_render(const RenderArgsBox B)
 {
+    const RenderArgs& A = B.a[0];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     LaneStack st;
     st.base = lds_dyn + wave * (A.stack_entries * 64u) + lane;
+    uint32_t* const lcg_skip = lds_dyn + (kRenderThreads / 64) * (A.stack_entries * 64u);      // 64 dwords behind the stacks
+    if (threadIdx.x < 32u) { lcg_skip[2u * threadIdx.x] = A.lcg_mul[threadIdx.x]; lcg_skip[2u * threadIdx.x + 1u] = A.lcg_add[threadIdx.x]; }
+    __syncthreads();
     const DeviceScene sc = A.scene;
     const ShadeConsts K = shade_consts(A);
     const f3 eye = mk(A.eye), camU = mk(A.U), camV = mk(A.V), camW = mk(A.W);
     const float fw = (float)(int)A.width, fh = (float)(int)A.height;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-    QueueState q; q.shard = xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0;
+    QueueState q; q.shard = xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.cur_slot = kNoSlot; q.cur_pxy = 0; q.cur_seed0 = 0; q.free0 = ~0ull; q.free1 = ~0ull;
     unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0;
+    uint32_t tick_lo = 0u, tick_hi = 0u;
+    float4* const scratch = A.wave_scratch + (size_t)(blockIdx.x * (kRenderThreads / 64) + wave) * ((size_t)kFoldSlots << A.chunk_shift);
 
-    LanePixel lp; lp.alive = false; lp.new_path = false; lp.pix = lp.px = lp.py = lp.seed = lp.samples_left = lp.chunk = 0; lp.result = mk(0.0f);
+    LanePixel lp; lp.alive = false; lp.new_path = false; lp.pxy = lp.seed = lp.samples_left = lp.tag = 0; lp.result = mk(0.0f);
     uint32_t pseed = 0;
     int depth = 0;
     f3 org = mk(0.0f), dir = mk(0.0f, 0.0f, 1.0f), att = mk(1.0f);
 
     for (;;) {
-        refill_lanes(A, q, lane, below, lp);
+        refill_lanes(A, q, lane, below, lp, lcg_skip);
         const unsigned long long live = vote(lp.alive);
         if (live == 0ull) { if (q.shards_left == 0u && q.res_count == 0u) break; else continue; }
 
         if (lp.alive && lp.new_path) {                                // camera path start, :727-745
             const float jx = rnd(lp.seed);
             const float jy = rnd(lp.seed);
-            const float dx = 2.0f * (((float)lp.px + jx) / fw) - 1.0f;
-            const float dy = 2.0f * (((float)lp.py + jy) / fh) - 1.0f;
-            dir = normalize(dx * camU + dy * camV + camW);
+            dir = normalize(camera_dir((float)(lp.pxy & 0xFFFFu), (float)(lp.pxy >> 16), jx, jy, fw, fh, camU, camV, camW));
             org = eye;
             att = mk(1.0f);
             pseed = lp.seed;
@@ -288,11 +407,12 @@ k_render(const RenderArgs A)
             } else {
                 lp.samples_left--;
                 lp.new_path = true;
-                if (lp.samples_left == 0u) { write_pixel(A, lp); lp.alive = false; finished = true; }
+                if (lp.samples_left == 0u) { lp.alive = false; finished = true; }
             }
         }
         n_paths += (unsigned long long)popc(vote(end));
         n_pixels += (unsigned long long)popc(vote(finished));
+        finish_runs(A, q, lp, finished, lane, tick_lo, tick_hi, scratch);
     }
     if (lane == 0) {
         atomicAdd(&A.counters[0], n_radiance);
@@ -361,8 +481,9 @@ __device__ __forceinline__ void setup_ray(const f3& ro, const f3& rd, const QGri
 // that many node visits per trip through the loop control.
 template <int SHADE_K, int LEAF_K, int NODE_FMT, int THREADS, int MINW, bool STATS, int DIAG = 0, int INNER = 0, int LEAVES = 1>
 __global__ void __launch_bounds__(THREADS, MINW)
-k_render_pw(const RenderArgs A)
+k_render_pw(const RenderArgsBox B)
 {
+    const RenderArgs& A = B.a[0];                     // what the BVH loop, the queue and the wave set-up use: read once
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     LaneStack st;
@@ -378,22 +499,23 @@ k_render_pw(const RenderArgs A)
         for (uint32_t i = threadIdx.x; i < A.n_lds_nodes * 2u; i += THREADS) dst[i] = src[i];
         __syncthreads();
     }
-    const QGrid G = sc.grid;
-    const HSpace HS = sc.hspace;
-    const ShadeConsts K = shade_consts(A);
-    const f3 eye = mk(A.eye), camU = mk(A.U), camV = mk(A.V), camW = mk(A.W);
-    const float fw = (float)(int)A.width, fh = (float)(int)A.height;
+    // LCG skip-ahead table behind the stacks (and behind the LDS-staged nodes of NODE_FMT 2)
+    uint32_t* const lcg_skip = lds_dyn + (THREADS / 64) * (A.stack_entries * 64u) + (NODE_FMT == 2 ? A.n_lds_nodes * 8u : 0u);
+    if (threadIdx.x < 32u) { lcg_skip[2u * threadIdx.x] = A.lcg_mul[threadIdx.x]; lcg_skip[2u * threadIdx.x + 1u] = A.lcg_add[threadIdx.x]; }
+    __syncthreads();
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int root = sc.n_tris ? 0 : kSentinel;
 
-    QueueState q; q.shard = xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0;
+    QueueState q; q.shard = xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.cur_slot = kNoSlot; q.cur_pxy = 0; q.cur_seed0 = 0; q.free0 = ~0ull; q.free1 = ~0ull;
+    uint32_t tick_lo = 0u, tick_hi = 0u;
+    float4* const scratch = A.wave_scratch + (size_t)(blockIdx.x * (THREADS / 64) + wave) * ((size_t)kFoldSlots << A.chunk_shift);
     unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0;
     unsigned long long n_steps = 0, n_lane_steps = 0, n_rounds = 0, n_lane_rounds = 0;
     // STATS only: 100 MHz stamps of this wave's start, of the moment it found the queue empty, and of its end
     unsigned long long t_start = 0, t_drain = 0, t_phase = 0, t_in_shade = 0;
     if (STATS) { t_start = __builtin_amdgcn_s_memrealtime(); t_phase = t_start; }
 
-    LanePixel lp; lp.alive = false; lp.new_path = false; lp.pix = lp.px = lp.py = lp.seed = lp.samples_left = lp.chunk = 0; lp.result = mk(0.0f);
+    LanePixel lp; lp.alive = false; lp.new_path = false; lp.pxy = lp.seed = lp.samples_left = lp.tag = 0; lp.result = mk(0.0f);
     uint32_t pseed = 0;
     int depth = 0;
     f3 att = mk(1.0f);
@@ -411,6 +533,14 @@ k_render_pw(const RenderArgs A)
 
     for (;;) {
         // =========================== shade / regenerate: lanes with no ray in flight ===============
+        const RenderArgs& R = B.a[opaque_zero()];                     // this round's view of the shading / camera constants
+        const QGrid G = R.scene.grid;
+        const HSpace HS = R.scene.hspace;
+        const ShadeConsts K = shade_consts(R);
+        const f3 eye = mk(R.eye), camU = mk(R.U), camV = mk(R.V), camW = mk(R.W);
+        const float fw = (float)(int)R.width, fh = (float)(int)R.height;
+        // camera-ray cull against the scene box (reaches_scene): corners relative to the eye; an empty scene is never reached
+        const f3 elo = R.scene.n_tris ? mk(R.cull_lo) - eye : mk(1.0f), ehi = R.scene.n_tris ? mk(R.cull_hi) - eye : mk(-1.0f);
         if (STATS) { n_rounds += 1; n_lane_rounds += (unsigned long long)popc(vote(lp.alive && node == kSentinel)); t_phase = __builtin_amdgcn_s_memrealtime(); }
         bool segment_done = false, started_shadow = false;
         f3 emission = mk(0.0f);
@@ -453,30 +583,50 @@ k_render_pw(const RenderArgs A)
             } else {
                 lp.samples_left--;
                 lp.new_path = true;
-                if (lp.samples_left == 0u) { write_pixel(A, lp); lp.alive = false; finished = true; }
+                if (lp.samples_left == 0u) { lp.alive = false; finished = true; }
             }
         }
         n_paths += (unsigned long long)popc(vote(end));
         n_pixels += (unsigned long long)popc(vote(finished));
+        finish_runs(A, q, lp, finished, lane, tick_lo, tick_hi, scratch);     // before the refill overwrites the lanes' items
 
-        refill_lanes<STATS>(A, q, lane, below, lp);
+        refill_lanes<STATS>(A, q, lane, below, lp, lcg_skip);
         if (STATS && t_drain == 0ull && q.shards_left == 0u && q.res_count == 0u) t_drain = __builtin_amdgcn_s_memrealtime();
-        if (vote(lp.alive) == 0ull) { if (q.shards_left == 0u && q.res_count == 0u) break; else continue; }
 
         bool start_radiance = segment_done && !end;
+        bool culled_out = false;
+        uint32_t my_culled = 0u;                                      // per lane: the counters are wave-uniform and must not be touched under divergence
         if (lp.alive && lp.new_path) {                                // camera path start, :727-745
-            const float jx = rnd(lp.seed);
-            const float jy = rnd(lp.seed);
-            const float dx = 2.0f * (((float)lp.px + jx) / fw) - 1.0f;
-            const float dy = 2.0f * (((float)lp.py + jy) / fh) - 1.0f;
-            rd = normalize(dx * camU + dy * camV + camW);
-            ro = eye;
-            att = mk(1.0f);
-            pseed = lp.seed;
-            depth = 0;
-            lp.new_path = false;
-            start_radiance = true;
+            f3 D;
+            for (;;) {
+                const float jx = rnd(lp.seed);
+                const float jy = rnd(lp.seed);
+                D = camera_dir((float)(lp.pxy & 0xFFFFu), (float)(lp.pxy >> 16), jx, jy, fw, fh, camU, camV, camW);
+                // a camera ray that cannot reach the scene box: one radiance segment that misses (:833-847 adds nothing to
+                // the result, done = true); its path ends here and the lane goes on to its next sample
+                if (reaches_scene(D, elo, ehi)) break;
+                my_culled++;
+                lp.samples_left--;
+                if (lp.samples_left == 0u) { lp.alive = false; culled_out = true; break; }
+            }
+            if (lp.alive) {
+                rd = normalize(D);
+                ro = eye;
+                att = mk(1.0f);
+                pseed = lp.seed;
+                depth = 0;
+                lp.new_path = false;
+                start_radiance = true;
+            }
         }
+        if (vote(my_culled != 0u) != 0ull) {                           // wave sum of the per-lane counts, bit plane by bit plane
+            unsigned long long sum = 0ull;
+            for (uint32_t b = 0; vote((my_culled >> b) != 0u) != 0ull; b++) sum += (unsigned long long)popc(vote(((my_culled >> b) & 1u) != 0u)) << b;
+            n_radiance += sum; n_paths += sum;
+        }
+        n_pixels += (unsigned long long)popc(vote(culled_out));
+        finish_runs(A, q, lp, culled_out, lane, tick_lo, tick_hi, scratch);
+        if (vote(lp.alive) == 0ull) { if (q.shards_left == 0u && q.res_count == 0u) break; else continue; }
         if (start_radiance) {                                         // traceRadiance :750-757
             setup_ray<NODE_FMT>(ro, rd, G, HS, rinv, gro);
             if (NODE_FMT == 8) rot = axis_rot(rinv);
@@ -755,12 +905,6 @@ __global__ void k_resolve(const float4* __restrict__ accum, uint32_t* __restrict
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { const float4 a = accum[i]; fb[i] = make_color(mk(a.x, a.y, a.z)); }
-}
-
-hipError_t launch_items(const RenderArgs& args, hipStream_t stream)
-{
-    k_items<<<(args.total_samples + 255) / 256, 256, 0, stream>>>(args);
-    return hipGetLastError();
 }
 
 hipError_t launch_finalize(const RenderArgs& args, hipStream_t stream)
@@ -1100,7 +1244,7 @@ hipError_t trace_stream_occupancy(int fmt, uint32_t stack_entries, int* blocks_p
 }
 
 // ---- host-side launchers ------------------------------------------------------------------
-typedef void (*RenderKernel)(const RenderArgs);
+typedef void (*RenderKernel)(const RenderArgsBox);
 
 struct VariantDesc { RenderKernel k; int threads; int node_fmt; const char* name; };
 
@@ -1164,7 +1308,7 @@ int render_variant_threads(int v) { return (v >= 0 && v < render_variant_count()
 
 static size_t variant_lds(const VariantDesc& d, uint32_t stack_entries, uint32_t n_nodes)
 {
-    size_t lds = (size_t)(d.threads / 64) * stack_entries * 256u;
+    size_t lds = (size_t)(d.threads / 64) * stack_entries * 256u + 256u;      // lane stacks + the LCG skip-ahead table
     if (d.node_fmt == 2) lds += (size_t)n_nodes * sizeof(QNode);
     return lds;
 }
@@ -1186,7 +1330,9 @@ hipError_t launch_render(int variant, const RenderArgs& args, uint32_t grid_bloc
     if (variant < 0 || variant >= render_variant_count()) return hipErrorInvalidValue;
     const VariantDesc& d = kVariants[variant];
     const size_t lds = variant_lds(d, args.stack_entries, args.n_lds_nodes);
-    hipLaunchKernelGGL(d.k, dim3(grid_blocks), dim3(d.threads), lds, stream, args);
+    RenderArgsBox box;
+    box.a[0] = args;
+    hipLaunchKernelGGL(d.k, dim3(grid_blocks), dim3(d.threads), lds, stream, box);
     return hipGetLastError();
 }
 
