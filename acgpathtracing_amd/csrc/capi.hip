@@ -87,7 +87,7 @@ PT_API int pt_create(pt_ctx** out, int device_id)
     memset(&c->stats, 0, sizeof(c->stats));
     if (hipStreamCreate(&c->own_stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipMalloc((void**)&c->d_queue, 8 * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void**)&c->d_counters, (8 + 3 * (size_t)ptd::kMaxTimedWaves + 2049) * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc((void**)&c->d_counters, (8 + 3 * (size_t)ptd::kMaxTimedWaves + 2056) * sizeof(unsigned long long)) != hipSuccess) {
         delete c;
         return fail(nullptr, "pt_create: device resource allocation failed");
     }
@@ -436,7 +436,7 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
         a.wave_scratch = c->d_wave_scratch;
     }
     CK(c, hipMemsetAsync(c->d_queue, 0, 8 * sizeof(uint32_t), c->stream));
-    CK(c, hipMemsetAsync(c->d_counters, 0, (8 + 3 * (size_t)ptd::kMaxTimedWaves + 2049) * sizeof(unsigned long long), c->stream));
+    CK(c, hipMemsetAsync(c->d_counters, 0, (8 + 3 * (size_t)ptd::kMaxTimedWaves + 2056) * sizeof(unsigned long long), c->stream));
     CK(c, hipEventRecord(c->ev0, c->stream));
     CK(c, ptd::launch_render(c->variant, a, grid, c->stream));
     CK(c, hipEventRecord(c->ev1, c->stream));
@@ -605,7 +605,7 @@ PT_API int pt_debug_queue_progress(pt_ctx* c, uint64_t* out)
 {
     if (!c || !out) return fail(c, "pt_debug_queue_progress: null argument");
     CK(c, hipSetDevice(c->device));
-    CK(c, hipMemcpy(out, c->d_counters + 8 + 3 * (size_t)ptd::kMaxTimedWaves, 2049 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    CK(c, hipMemcpy(out, c->d_counters + 8 + 3 * (size_t)ptd::kMaxTimedWaves, 2056 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return 0;
 }
 

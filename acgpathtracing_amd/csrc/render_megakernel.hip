@@ -53,7 +53,8 @@ constexpr uint32_t kNoSlot = 0xFFu;
 struct QueueState {
     uint32_t shard, shards_left, res_first, res_count;
     uint32_t cur_slot;                    // slot of the group the reserve currently stands inside (kNoSlot: padding group)
-    uint32_t cur_pxy, cur_seed0;          // that group's pixel and tea<4> seed (valid while cur_slot != kNoSlot)
+    uint32_t grant_g0;                    // first group of the current grant
+    uint32_t grp_pxy, grp_seed;           // PER LANE: lane j holds pixel (x | y << 16, 0xFFFFFFFF = padding) and tea<4> seed of group grant_g0 + j
     unsigned long long free0, free1;      // free fold slots 0..63, 64..127
 };
 
@@ -134,6 +135,18 @@ __device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q,
             if (avail < req) { q.shard = (q.shard + 1u) & 7u; q.shards_left--; }   // shard drained: steal from the next
             q.res_first = first; q.res_count = avail;
             if (avail == 0u) continue;
+            if (cs != 0u) {
+                // decode the grant's groups side by side, one per lane (<= 48 of them): tile order -> pixel, tea<4> seed (:721).
+                // Once per grant instead of one serial tea<4> chain per group on the deal's critical path.
+                q.grant_g0 = first >> cs;
+                const uint32_t g = q.grant_g0 + lane;
+                uint32_t x, y;
+                sample_pixel_fast(A, g >> fshift, x, y);
+                const uint32_t f = g & fmask;
+                const bool ok = (g << cs) < first + avail && x < A.width && y < A.height && f < A.n_frames;   // else: padding of the tile / batch grid
+                q.grp_pxy = ok ? (x | (y << 16)) : 0xFFFFFFFFu;
+                q.grp_seed = tea4(y * A.width + x, A.frame + f);
+            }
         }
         const uint32_t want = (uint32_t)popc(idle);
         uint32_t take = want < q.res_count ? want : q.res_count;
@@ -154,27 +167,26 @@ __device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q,
                 lp.new_path = true;
             }
         } else {
-            // Several runs per group.  The deal touches <= take / runs + 1 consecutive groups; each is decoded ONCE, on
-            // wave-uniform values (scalar unit: tile order -> pixel, tea<4> seed), gets its fold slot, and the lanes that
-            // drew one of its runs copy the result and skip the LCG ahead to their run.
+            // Several runs per group.  The deal touches <= take / runs + 1 consecutive groups of the current grant (decoded when
+            // the grant was fetched); each gets its fold slot when its first run is dealt, and the lanes that drew one of its
+            // runs copy pixel and seed and skip the LCG ahead to their run.
             const uint32_t g_first = q.res_first >> cs, g_last = (q.res_first + take - 1u) >> cs;
             const uint32_t my_g = item >> cs;
             const uint32_t run = item & run_mask;
             for (uint32_t g = g_first; g <= g_last; g++) {
                 const uint32_t f = g & fmask;
-                uint32_t sl, pxy, seed0;
-                if ((g << cs) < q.res_first) {                         // the group the previous deal stopped inside: decoded then
-                    sl = q.cur_slot; pxy = q.cur_pxy; seed0 = q.cur_seed0;
+                const uint32_t pxy = (uint32_t)__builtin_amdgcn_readlane((int)q.grp_pxy, (int)(g - q.grant_g0));
+                const uint32_t seed0 = (uint32_t)__builtin_amdgcn_readlane((int)q.grp_seed, (int)(g - q.grant_g0));
+                uint32_t sl;
+                if ((g << cs) < q.res_first) {
+                    sl = q.cur_slot;                                   // the group the previous deal stopped inside
                 } else {
-                    uint32_t x, y;
-                    sample_pixel_fast(A, g >> fshift, x, y);
-                    sl = kNoSlot; pxy = x | (y << 16); seed0 = 0u;
-                    if (x < A.width && y < A.height && f < A.n_frames) {   // else: padding of the tile / batch grid
+                    sl = kNoSlot;
+                    if (pxy != 0xFFFFFFFFu) {
                         sl = alloc_slot(q);
                         if (sl == kNoSlot) { take = (g << cs) - q.res_first; break; }   // cannot happen (see above); deal the rest next round
-                        seed0 = tea4(y * A.width + x, A.frame + f);    // :721
                     }
-                    q.cur_slot = sl; q.cur_pxy = pxy; q.cur_seed0 = seed0;
+                    q.cur_slot = sl;
                 }
                 if (sl != kNoSlot && !lp.alive && rank < take && my_g == g) {
                     lp.pxy = pxy;
@@ -222,6 +234,22 @@ __device__ __forceinline__ void write_frame_sum(const RenderArgs& A, uint32_t pi
     else A.frame_sums[(size_t)pix * A.n_frames + f] = make_float4(sum.x, sum.y, sum.z, 0.0f);
 }
 
+// Two / four consecutive 16-byte loads served by the L2 (sc1: agent scope), not by whatever an earlier use of the addresses
+// left in this CU's L1, all in flight together and waited for inside the same asm block (the compiler never sees a
+// register whose load has not landed).
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load2_coherent(const float4* p, v4f_t& a, v4f_t& b)
+{
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void load4_coherent(const float4* p, v4f_t& a, v4f_t& b, v4f_t& c, v4f_t& d)
+{
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p) : "memory");
+}
+
 // Lanes with `finished` set have completed their run of samples.  One run per pixel: write.  Several: park the partial
 // sum in the group's fold slot, bump the ticket, and let the lane that completes the group add the runs in order.
 // tick_lo / tick_hi: lane s holds the ticket of slot s / 64 + s.  scratch: this wave's kFoldSlots << chunk_shift float4.
@@ -256,13 +284,22 @@ __device__ __forceinline__ void finish_runs(const RenderArgs& A, QueueState& q, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0) only
     if ((folders >> lane) & 1ull) {
-        const uint32_t* g = (const uint32_t*)group;
+        // the loads of four runs in flight at once (one latency per four runs, not one per run)
         f3 sum = mk(0.0f);
-        for (uint32_t k = 0; k < runs; k++) {
-            const float vx = __uint_as_float(__hip_atomic_load(g + 4u * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            const float vy = __uint_as_float(__hip_atomic_load(g + 4u * k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            const float vz = __uint_as_float(__hip_atomic_load(g + 4u * k + 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if (k == 0u) sum = mk(vx, vy, vz); else sum += mk(vx, vy, vz);      // the chain starts at run 0, not at zero
+        if (runs == 2u) {
+            v4f_t p0, p1;
+            load2_coherent(group, p0, p1);
+            sum = mk(p0.x, p0.y, p0.z);
+            sum += mk(p1.x, p1.y, p1.z);
+        } else {
+            for (uint32_t k0 = 0; k0 < runs; k0 += 4u) {
+                v4f_t p0, p1, p2, p3;
+                load4_coherent(group + k0, p0, p1, p2, p3);
+                if (k0 == 0u) sum = mk(p0.x, p0.y, p0.z); else sum += mk(p0.x, p0.y, p0.z);      // the chain starts at run 0, not at zero
+                sum += mk(p1.x, p1.y, p1.z);
+                sum += mk(p2.x, p2.y, p2.z);
+                sum += mk(p3.x, p3.y, p3.z);
+            }
         }
         write_frame_sum(A, pixel_index(A, lp), sub >> cs, sum);
     }
@@ -346,7 +383,7 @@ k_render(const RenderArgsBox B)
     const float fw = (float)(int)A.width, fh = (float)(int)A.height;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-    QueueState q; q.shard = xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.cur_slot = kNoSlot; q.cur_pxy = 0; q.cur_seed0 = 0; q.free0 = ~0ull; q.free1 = ~0ull;
+    QueueState q; q.shard = xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.cur_slot = kNoSlot; q.grant_g0 = 0; q.grp_pxy = 0xFFFFFFFFu; q.grp_seed = 0; q.free0 = ~0ull; q.free1 = ~0ull;
     unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0;
     uint32_t tick_lo = 0u, tick_hi = 0u;
     float4* const scratch = A.wave_scratch + (size_t)(blockIdx.x * (kRenderThreads / 64) + wave) * ((size_t)kFoldSlots << A.chunk_shift);
@@ -506,13 +543,13 @@ k_render_pw(const RenderArgsBox B)
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int root = sc.n_tris ? 0 : kSentinel;
 
-    QueueState q; q.shard = xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.cur_slot = kNoSlot; q.cur_pxy = 0; q.cur_seed0 = 0; q.free0 = ~0ull; q.free1 = ~0ull;
+    QueueState q; q.shard = xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.cur_slot = kNoSlot; q.grant_g0 = 0; q.grp_pxy = 0xFFFFFFFFu; q.grp_seed = 0; q.free0 = ~0ull; q.free1 = ~0ull;
     uint32_t tick_lo = 0u, tick_hi = 0u;
     float4* const scratch = A.wave_scratch + (size_t)(blockIdx.x * (THREADS / 64) + wave) * ((size_t)kFoldSlots << A.chunk_shift);
     unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0;
     unsigned long long n_steps = 0, n_lane_steps = 0, n_rounds = 0, n_lane_rounds = 0;
     // STATS only: 100 MHz stamps of this wave's start, of the moment it found the queue empty, and of its end
-    unsigned long long t_start = 0, t_drain = 0, t_phase = 0, t_in_shade = 0;
+    unsigned long long t_start = 0, t_drain = 0, t_phase = 0, t_in_shade = 0, t_refill = 0, t_finish = 0, t_newpath = 0, t_mark = 0;
     if (STATS) { t_start = __builtin_amdgcn_s_memrealtime(); t_phase = t_start; }
 
     LanePixel lp; lp.alive = false; lp.new_path = false; lp.pxy = lp.seed = lp.samples_left = lp.tag = 0; lp.result = mk(0.0f);
@@ -588,9 +625,12 @@ k_render_pw(const RenderArgsBox B)
         }
         n_paths += (unsigned long long)popc(vote(end));
         n_pixels += (unsigned long long)popc(vote(finished));
+        if (STATS) t_mark = __builtin_amdgcn_s_memrealtime();
         finish_runs(A, q, lp, finished, lane, tick_lo, tick_hi, scratch);     // before the refill overwrites the lanes' items
+        if (STATS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); t_finish += now - t_mark; t_mark = now; }
 
         refill_lanes<STATS>(A, q, lane, below, lp, lcg_skip);
+        if (STATS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); t_refill += now - t_mark; t_mark = now; }
         if (STATS && t_drain == 0ull && q.shards_left == 0u && q.res_count == 0u) t_drain = __builtin_amdgcn_s_memrealtime();
 
         bool start_radiance = segment_done && !end;
@@ -625,7 +665,9 @@ k_render_pw(const RenderArgsBox B)
             n_radiance += sum; n_paths += sum;
         }
         n_pixels += (unsigned long long)popc(vote(culled_out));
+        if (STATS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); t_newpath += now - t_mark; t_mark = now; }
         finish_runs(A, q, lp, culled_out, lane, tick_lo, tick_hi, scratch);
+        if (STATS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); t_finish += now - t_mark; }
         if (vote(lp.alive) == 0ull) { if (q.shards_left == 0u && q.res_count == 0u) break; else continue; }
         if (start_radiance) {                                         // traceRadiance :750-757
             setup_ray<NODE_FMT>(ro, rd, G, HS, rinv, gro);
@@ -895,6 +937,9 @@ k_render_pw(const RenderArgsBox B)
                 A.counters[8 + 3 * w] = t_start;
                 A.counters[8 + 3 * w + 1] = t_drain;
                 atomicAdd(&A.counters[8 + 3 * kMaxTimedWaves + 2048], t_in_shade);       // 10 ns units, summed over waves
+                atomicAdd(&A.counters[8 + 3 * kMaxTimedWaves + 2049], t_refill);         // ... of which: queue refill,
+                atomicAdd(&A.counters[8 + 3 * kMaxTimedWaves + 2050], t_finish);         // finished runs (park / fold / write),
+                atomicAdd(&A.counters[8 + 3 * kMaxTimedWaves + 2051], t_newpath);        // camera-path start incl. the cull
                 A.counters[8 + 3 * w + 2] = __builtin_amdgcn_s_memrealtime();
             }
         }

@@ -247,7 +247,7 @@ int pt_selftest(pt_ctx* ctx, int op, const void* in, size_t n, void* out);
 int pt_debug_wave_times(pt_ctx* ctx, uint64_t* out, size_t max_waves);
 /* ... and, per work-queue shard (8), the stamp of the first grant past each 1/256 of the shard: HOST output of
  * 8 * 256 values (0 = never reached by a stamped grant), followed by ONE value: the time all waves together spent
- * in the shade / regenerate phase, in 10 ns units (2049 values in all). */
+ * in the shade / regenerate phase, in 10 ns units and its split into queue refill / finished runs / camera-path start (2056 values in all: 2048 + 1 + 3, rest unused). */
 int pt_debug_queue_progress(pt_ctx* ctx, uint64_t* out);
 /* Sorted (morton, triangle) pairs of the last build, HOST outputs of n_tris. */
 int pt_read_morton(pt_ctx* ctx, uint32_t* codes_sorted, uint32_t* prims_sorted);

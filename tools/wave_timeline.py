@@ -57,9 +57,12 @@ def main():
     print("after the queue was empty, per wave %s" % q(end - drain))
     busy = (end - start).sum(); tail = (end - drain).sum()
     print("wave-time spent after the queue was empty: %.2f %% of all wave-time; last wave ends %.3f ms after the median wave" % (100 * tail / busy, end.max() - np.median(end)))
-    pr = np.zeros(2049, np.uint64)
+    pr = np.zeros(2056, np.uint64)
     assert L.pt_debug_queue_progress(state.context, pr.ctypes.data) == 0
     print("share of the wave-time spent in the shade / regenerate phase (the rest is the BVH loop): %.1f %%" % (100.0 * float(pr[2048]) / 1e5 / busy))
+    print("   of the wave-time: queue refill %.1f %%, finished runs (park / fold / write) %.1f %%, camera-path start incl. cull %.1f %%" %
+          tuple(100.0 * float(pr[2049 + k]) / 1e5 / busy for k in range(3)))
+    print("   shade rounds %d, lanes shaded per round %.1f; BVH loop trips %d at %.1f lanes" % (s.shade_wave_rounds, s.shade_lane_rounds / max(1, s.shade_wave_rounds), s.trav_wave_steps, s.trav_lane_steps / max(1, s.trav_wave_steps)))
     pr = pr[:2048].reshape(8, 256).astype(np.float64)
     print("work-queue progress (all shards advance together unless noted): time at which each tenth of the items had been handed out, and the rate between them")
     frac = []
