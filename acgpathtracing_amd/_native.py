@@ -78,6 +78,8 @@ _host = None
 def hip_library_path():
     # ACGPT_EXPERIMENTS=1 (tools/sweep_variants.py only): the build that also carries the kernel variants that were
     # measured and not adopted.  Same sources, same ABI; never what tests, smoke() or bench.py load by default.
+    if os.environ.get("ACGPT_HIP_LIB"):          # A/B measurements of differently built libraries (tools/ only)
+        return os.path.join(PKG, os.environ["ACGPT_HIP_LIB"])
     if os.environ.get("ACGPT_EXPERIMENTS") == "1":
         return os.path.join(PKG, "libacgpt_hip_exp.so")
     return os.path.join(PKG, "libacgpt_hip.so")

@@ -390,7 +390,7 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
         !check_fast_div(a.div_world, (uint32_t)c->world, 65536u + (uint32_t)c->world))
         return fail(c, "pt_launch: internal error (division constants)");
     a.shard_size = ((a.total_samples + 7u) / 8u + 63u) & ~63u;
-    if (n_frames > 1u) {
+    {   // one float4 per (pixel, sub-frame): what the megakernel hands to k_finalize
         const size_t need = (size_t)p->width * p->height * n_frames * sizeof(float4);
         if (need > c->frame_sums_bytes) {
             CK(c, hipStreamSynchronize(c->stream));
@@ -440,7 +440,7 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
     CK(c, hipEventRecord(c->ev0, c->stream));
     CK(c, ptd::launch_render(c->variant, a, grid, c->stream));
     CK(c, hipEventRecord(c->ev1, c->stream));
-    if (n_frames > 1u) CK(c, ptd::launch_finalize(a, c->stream));
+    CK(c, ptd::launch_finalize(a, c->stream));
     unsigned long long h[8];
     CK(c, hipMemcpyAsync(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     CK(c, hipStreamSynchronize(c->stream));            // CUDA_SYNC_CHECK, PathTracerMain.cpp:209

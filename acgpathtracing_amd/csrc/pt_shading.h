@@ -143,12 +143,10 @@ __device__ __forceinline__ uint32_t xcc_id()
 }
 
 
-// Launch constants the shading needs, hoisted once per wave.
-struct ShadeConsts {
-    f3 Lc, Lv1, Lv2, Ln, Le;
-    float lightA;
-    uint32_t useDL, useIS;
-};
+// What the shading needs of the launch constants (toggles, area light) is read where it is used, through `late()`: a
+// callable that returns the kernel's RenderArgs.  The persistent kernel passes one that re-reads the kernel-argument
+// segment at that point (render_megakernel.hip, RenderArgsBox), so that these ~20 values are never held in scalar
+// registers across the rest of the kernel; a plain `return A` keeps the compiler's usual hoisting.
 
 // What a closest-hit leaves behind for raygen (RadiancePayloadRayData, pathTracer.h:19-32), minus
 // what is consumed on the spot.
@@ -163,8 +161,8 @@ struct Pending {
 // TRIG_DIAG (kernel variant 10, opt-in): the cosine-weighted sampler with v_sin_f32 / v_cos_f32 and sqrt(1 - z1) for
 // sin(acos(sqrt(z1))) — the kind of arithmetic the reference's own build uses (nvcc --use_fast_math, CMakeLists.txt:267).
 // Different low bits than the default path, same image within the parity tolerance (test_fast_math_variant).
-template <bool TRIG_DIAG = false>
-__device__ __forceinline__ bool shade_hit(const DeviceScene& sc, const ShadeConsts& K, const f3& org, const f3& dir,
+template <bool TRIG_DIAG = false, typename Late>
+__device__ __forceinline__ bool shade_hit(const DeviceScene& sc, Late late, const f3& org, const f3& dir,
                                           float t_hit, int slot, int depth, uint32_t& pseed, f3& att, f3& emission,
                                           Pending& pd, f3& P, f3& L, float& Ldist)
 {
@@ -184,7 +182,7 @@ __device__ __forceinline__ bool shade_hit(const DeviceScene& sc, const ShadeCons
         const float z1 = rnd(s);
         const float z2 = rnd(s);
         f3 w_in;
-        if (K.useIS) w_in = TRIG_DIAG ? cosine_sample_hemisphere_fast(z1, z2) : cosine_sample_hemisphere(z1, z2);
+        if (late().useIS) w_in = TRIG_DIAG ? cosine_sample_hemisphere_fast(z1, z2) : cosine_sample_hemisphere(z1, z2);
         else         w_in = uniform_sample_hemisphere(z1, z2);
         onb_transform(N, w_in);
         pd.nxt_dir = w_in;
@@ -221,14 +219,15 @@ __device__ __forceinline__ bool shade_hit(const DeviceScene& sc, const ShadeCons
     else                   { pd.radiance = mk(0.0f); pd.done = false; }
     pd.weight = 0.0f;
     bool want_shadow = false;
-    if (K.useDL && bsdf != PT_BSDF_REFRACTION) {                                 // :1003-1026
-        const f3 light_pos = K.Lc + K.Lv1 * z1 + K.Lv2 * z2;
+    const auto& La = late();
+    if (La.useDL && bsdf != PT_BSDF_REFRACTION) {                                // :1003-1026
+        const f3 light_pos = mk(La.light.corner) + mk(La.light.v1) * z1 + mk(La.light.v2) * z2;
         Ldist = length(light_pos - P);
         L = normalize(light_pos - P);
         const float nDl = dot(N, L);
-        const float LnDl = -dot(K.Ln, L);
+        const float LnDl = -dot(mk(La.light.normal), L);
         want_shadow = nDl > 0.0f && LnDl > 0.0f;
-        pd.weight = nDl * LnDl * K.lightA / (kPIf * Ldist * Ldist);              // :1022, used only if unoccluded
+        pd.weight = nDl * LnDl * La.light_area / (kPIf * Ldist * Ldist);         // :1021-1022 (|v1 x v2| from the host), used only if unoccluded
     }
     return want_shadow;
 }

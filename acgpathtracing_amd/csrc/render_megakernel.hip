@@ -6,7 +6,7 @@
 //
 // Kernels of one pt_launch, in stream order:
 //   k_render_pw  the persistent megakernel (default; k_render = segment-synchronous baseline)
-//   k_finalize   only for a batch of several sub-frames: folds the sub-frames into the accumulation buffer in order
+//   k_finalize   blends the launch's sub-frame(s) into the accumulation buffer in frame order, make_color
 //
 // Scheduling (wave64, persistent):
 //   * the grid is sized to the chip (CUs x resident workgroups), never to the image;
@@ -106,11 +106,11 @@ __device__ __forceinline__ void sample_pixel_fast(const RenderArgs& A, uint32_t 
 // in the kernel-argument segment would be a global load on the deal's critical path)
 template <bool STATS = false>
 __device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q, uint32_t lane, unsigned long long below, LanePixel& lp,
-                                             const uint32_t* lcg_skip)
+                                             const uint32_t* lcg_skip, bool hold = false)
 {
     const uint32_t cs = A.chunk_shift, run_mask = (1u << cs) - 1u;
     const uint32_t fshift = A.sub_shift - cs, fmask = (1u << fshift) - 1u;      // group index = pixel slot << fshift | sub-frame
-    unsigned long long idle = vote(!lp.alive);
+    unsigned long long idle = vote(!lp.alive && !hold);
     while (idle != 0ull && (q.res_count != 0u || q.shards_left != 0u)) {
         if (q.res_count == 0u) {                                      // wave-uniform: fetch a grant
             const uint32_t leader = (uint32_t)__ffsll((long long)idle) - 1u;
@@ -201,7 +201,7 @@ __device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q,
         }
         q.res_first += take; q.res_count -= take;
         if (take == 0u) break;
-        idle = vote(!lp.alive);          // lanes that drew a padding item try again
+        idle = vote(!lp.alive && !hold);          // lanes that drew a padding item try again
     }
 }
 
@@ -216,22 +216,12 @@ __device__ __forceinline__ f3 blend_frame(const f3& prev, const f3& result, uint
     return accum;
 }
 
-// one sub-frame: blend, float4 + sRGB write (:782-814)
-__device__ __forceinline__ void resolve_pixel(const RenderArgs& A, uint32_t pix, const f3& result)
-{
-    f3 prev = mk(0.0f);
-    if (A.frame > 0u) { const float4 p = A.accum[pix]; prev = mk(p.x, p.y, p.z); }
-    const f3 accum = blend_frame(prev, result, A.spp, A.frame);
-    A.accum[pix] = make_float4(accum.x, accum.y, accum.z, 1.0f);
-    if (A.fb) A.fb[pix] = make_color(accum);
-}
-
-// the sum of one (pixel, sub-frame) is complete: a single launch step resolves the pixel right away; inside a batch the
-// sum is parked per (pixel, sub-frame) and k_finalize blends the sub-frames in frame order
+// the sum of one (pixel, sub-frame) is complete: it is parked per (pixel, sub-frame); k_finalize blends the sub-frames of
+// the launch into the accumulation buffer in frame order and applies make_color (the megakernel carries neither: their
+// powf code would be inlined at every place a lane can finish)
 __device__ __forceinline__ void write_frame_sum(const RenderArgs& A, uint32_t pix, uint32_t f, const f3& sum)
 {
-    if (A.n_frames == 1u) resolve_pixel(A, pix, sum);
-    else A.frame_sums[(size_t)pix * A.n_frames + f] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+    A.frame_sums[(size_t)pix * A.n_frames + f] = make_float4(sum.x, sum.y, sum.z, 0.0f);
 }
 
 // Two / four consecutive 16-byte loads served by the L2 (sc1: agent scope), not by whatever an earlier use of the addresses
@@ -327,15 +317,6 @@ __global__ void __launch_bounds__(kFinThreads) k_finalize(const RenderArgs A)
     if (A.fb) A.fb[pix] = make_color(accum);
 }
 
-__device__ __forceinline__ ShadeConsts shade_consts(const RenderArgs& A)
-{
-    ShadeConsts K;
-    K.Lc = mk(A.light.corner); K.Lv1 = mk(A.light.v1); K.Lv2 = mk(A.light.v2); K.Ln = mk(A.light.normal); K.Le = mk(A.light.emission);
-    K.lightA = A.light_area;                                        // :1021 |v1 x v2|, evaluated once on the host with the same fp32 operations
-    K.useDL = A.useDL; K.useIS = A.useIS;
-    return K;
-}
-
 // Camera ray through pixel (px, py) with jitter (jx, jy), unnormalised (:730-737)
 __device__ __forceinline__ f3 camera_dir(float px, float py, float jx, float jy, float fw, float fh, const f3& U, const f3& V, const f3& W)
 {
@@ -378,7 +359,7 @@ k_render(const RenderArgsBox B)
     if (threadIdx.x < 32u) { lcg_skip[2u * threadIdx.x] = A.lcg_mul[threadIdx.x]; lcg_skip[2u * threadIdx.x + 1u] = A.lcg_add[threadIdx.x]; }
     __syncthreads();
     const DeviceScene sc = A.scene;
-    const ShadeConsts K = shade_consts(A);
+    const auto late = [&]() -> const RenderArgs& { return A; };
     const f3 eye = mk(A.eye), camU = mk(A.U), camV = mk(A.V), camW = mk(A.W);
     const float fw = (float)(int)A.width, fh = (float)(int)A.height;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -419,14 +400,14 @@ k_render(const RenderArgsBox B)
         pd.done = true;                                               // __miss__ms :833-847
         bool want_shadow = false;
         if (lp.alive && hit.slot >= 0)
-            want_shadow = shade_hit(sc, K, org, dir, hit.t, hit.slot, depth, pseed, att, emission, pd, P, L, Ldist);
+            want_shadow = shade_hit(sc, late, org, dir, hit.t, hit.slot, depth, pseed, att, emission, pd, P, L, Ldist);
 
         const unsigned long long shadow_mask = vote(want_shadow);
         if (shadow_mask != 0ull) {                                    // traceOcclusion :651-684
             HitRec sh;
             const bool occluded = traverse<true>(sc, st, want_shadow, P, L, 0.01f, Ldist - 0.01f, sh);
             n_shadow += (unsigned long long)popc(shadow_mask);
-            if (want_shadow && !occluded) pd.radiance += K.Le * pd.weight;
+            if (want_shadow && !occluded) pd.radiance += mk(A.light.emission) * pd.weight;
         }
 
         bool end = false, finished = false;
@@ -565,39 +546,34 @@ k_render_pw(const RenderArgsBox B)
     int node = kSentinel, sp = 0, tos = kSentinel;
     uint32_t cur_base = 0, cur_list = 0;              // NODE_FMT 3: innermost group of pending children
     bool shadow_ray = false, shadow_hit = false;
+    bool fin_pending = false;                         // ran out of samples inside the camera cull: its run is finished at the next round's start
     // held while the shadow ray is in flight
     Pending pd; pd.nxt_org = mk(0.0f); pd.nxt_dir = mk(0.0f, 0.0f, 1.0f); pd.radiance = mk(0.0f); pd.weight = 0.0f; pd.done = true;
 
     for (;;) {
         // =========================== shade / regenerate: lanes with no ray in flight ===============
-        const RenderArgs& R = B.a[opaque_zero()];                     // this round's view of the shading / camera constants
-        const QGrid G = R.scene.grid;
-        const HSpace HS = R.scene.hspace;
-        const ShadeConsts K = shade_consts(R);
-        const f3 eye = mk(R.eye), camU = mk(R.U), camV = mk(R.V), camW = mk(R.W);
-        const float fw = (float)(int)R.width, fh = (float)(int)R.height;
-        // camera-ray cull against the scene box (reaches_scene): corners relative to the eye; an empty scene is never reached
-        const f3 elo = R.scene.n_tris ? mk(R.cull_lo) - eye : mk(1.0f), ehi = R.scene.n_tris ? mk(R.cull_hi) - eye : mk(-1.0f);
+        // launch constants the shade phase needs are read at their points of use (see RenderArgsBox above)
+        const auto late = [&]() -> const RenderArgs& { return B.a[opaque_zero()]; };
         if (STATS) { n_rounds += 1; n_lane_rounds += (unsigned long long)popc(vote(lp.alive && node == kSentinel)); t_phase = __builtin_amdgcn_s_memrealtime(); }
         bool segment_done = false, started_shadow = false;
         f3 emission = mk(0.0f);
         if (lp.alive && node == kSentinel) {
             if (shadow_ray) {                                         // shadow ray back (:1015-1024)
-                if (!shadow_hit) pd.radiance += K.Le * pd.weight;
+                if (!shadow_hit) pd.radiance += mk(late().light.emission) * pd.weight;
                 shadow_ray = false;
                 segment_done = true;
             } else {                                                  // radiance ray back
                 bool want_shadow = false;
                 f3 P, L; float Ldist;
                 if (best_slot >= 0) {
-                    want_shadow = shade_hit<DIAG == 3>(sc, K, ro, rd, best_t, best_slot, depth, pseed, att, emission, pd, P, L, Ldist);
+                    want_shadow = shade_hit<DIAG == 3>(sc, late, ro, rd, best_t, best_slot, depth, pseed, att, emission, pd, P, L, Ldist);
                 } else {                                              // __miss__ms :833-847
                     pd.radiance = mk(0.0f); pd.weight = 0.0f; pd.done = true;
                 }
                 lp.result += emission;                                // :760 (before the radiance term)
                 if (want_shadow) {
                     ro = P; rd = L;
-                    setup_ray<NODE_FMT>(ro, rd, G, HS, rinv, gro);
+                    { const RenderArgs& Rs = late(); setup_ray<NODE_FMT>(ro, rd, Rs.scene.grid, Rs.scene.hspace, rinv, gro); }
                     if (NODE_FMT == 8) rot = axis_rot(rinv);
                     rtmax = Ldist - 0.01f; best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu;
                     node = root; sp = 0; cur_list = 0u; shadow_ray = true; shadow_hit = false; started_shadow = true;
@@ -624,6 +600,8 @@ k_render_pw(const RenderArgsBox B)
             }
         }
         n_paths += (unsigned long long)popc(vote(end));
+        finished = finished || fin_pending;
+        fin_pending = false;
         n_pixels += (unsigned long long)popc(vote(finished));
         if (STATS) t_mark = __builtin_amdgcn_s_memrealtime();
         finish_runs(A, q, lp, finished, lane, tick_lo, tick_hi, scratch);     // before the refill overwrites the lanes' items
@@ -634,9 +612,13 @@ k_render_pw(const RenderArgsBox B)
         if (STATS && t_drain == 0ull && q.shards_left == 0u && q.res_count == 0u) t_drain = __builtin_amdgcn_s_memrealtime();
 
         bool start_radiance = segment_done && !end;
-        bool culled_out = false;
         uint32_t my_culled = 0u;                                      // per lane: the counters are wave-uniform and must not be touched under divergence
         if (lp.alive && lp.new_path) {                                // camera path start, :727-745
+            const RenderArgs& Rc = late();
+            const f3 eye = mk(Rc.eye), camU = mk(Rc.U), camV = mk(Rc.V), camW = mk(Rc.W);
+            const float fw = (float)(int)Rc.width, fh = (float)(int)Rc.height;
+            // camera-ray cull against the scene box (reaches_scene): corners relative to the eye; an empty scene is never reached
+            const f3 elo = Rc.scene.n_tris ? mk(Rc.cull_lo) - eye : mk(1.0f), ehi = Rc.scene.n_tris ? mk(Rc.cull_hi) - eye : mk(-1.0f);
             f3 D;
             for (;;) {
                 const float jx = rnd(lp.seed);
@@ -647,7 +629,7 @@ k_render_pw(const RenderArgsBox B)
                 if (reaches_scene(D, elo, ehi)) break;
                 my_culled++;
                 lp.samples_left--;
-                if (lp.samples_left == 0u) { lp.alive = false; culled_out = true; break; }
+                if (lp.samples_left == 0u) { lp.alive = false; fin_pending = true; break; }
             }
             if (lp.alive) {
                 rd = normalize(D);
@@ -664,13 +646,10 @@ k_render_pw(const RenderArgsBox B)
             for (uint32_t b = 0; vote((my_culled >> b) != 0u) != 0ull; b++) sum += (unsigned long long)popc(vote(((my_culled >> b) & 1u) != 0u)) << b;
             n_radiance += sum; n_paths += sum;
         }
-        n_pixels += (unsigned long long)popc(vote(culled_out));
-        if (STATS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); t_newpath += now - t_mark; t_mark = now; }
-        finish_runs(A, q, lp, culled_out, lane, tick_lo, tick_hi, scratch);
-        if (STATS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); t_finish += now - t_mark; }
-        if (vote(lp.alive) == 0ull) { if (q.shards_left == 0u && q.res_count == 0u) break; else continue; }
+        if (STATS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); t_newpath += now - t_mark; }
+        if (vote(lp.alive) == 0ull) { if (q.shards_left == 0u && q.res_count == 0u && vote(fin_pending) == 0ull) break; else continue; }
         if (start_radiance) {                                         // traceRadiance :750-757
-            setup_ray<NODE_FMT>(ro, rd, G, HS, rinv, gro);
+            { const RenderArgs& Rs = late(); setup_ray<NODE_FMT>(ro, rd, Rs.scene.grid, Rs.scene.hspace, rinv, gro); }
             if (NODE_FMT == 8) rot = axis_rot(rinv);
             rtmax = 1e16f; best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu;
             node = root; sp = 0; cur_list = 0u; shadow_ray = false;
