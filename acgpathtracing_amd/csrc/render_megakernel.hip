@@ -42,20 +42,34 @@ extern __shared__ uint32_t lds_dyn[];
 // popcount-prefix and keeps the rest as a reserve, so most refills touch no atomic at all.  Shards are per XCD;
 // drained shards are stolen from round-robin.
 //
-// Fold slots: all runs of one (pixel, sub-frame) are granted to ONE wave (grants are whole groups).  A group gets a
-// slot of the wave's scratch when its first run is dealt; a lane that finishes a run parks its partial sum there and
-// bumps the slot's ticket (a wave-local counter: lane s of two registers holds the count of slot s); the lane that
-// brings the ticket to the run count adds the partial sums in run order — the association orc_render(chunks) uses —
-// and writes the pixel.  Open groups per wave <= 64 lanes + 1 partially dealt, slots 128.
+// Fold slots: all runs of one (pixel, sub-frame) are granted to ONE wave (grants are whole groups).  Every group of a grant
+// gets a slot of the wave's scratch when the grant is fetched (popped from the wave's free list in LDS); a lane that
+// finishes a run parks its partial sum there and bumps the slot's ticket (an LDS counter, one ds_add_rtn for all the lanes
+// that finish in a round); the lane that brings the ticket to the run count adds the partial sums in run order — the
+// association orc_render(chunks) uses —, writes the sum and pushes the slot back.  Open groups per wave <= 64 lanes
+// in flight + one grant (<= 48 groups), slots 128.
 constexpr uint32_t kFoldSlots = 128u;
 constexpr uint32_t kNoSlot = 0xFFu;
+constexpr uint32_t kBookDwords = 2u * kFoldSlots + 8u;        // per wave in LDS: tickets, free-slot stack, its height (+ padding)
+
+struct WaveBook {
+    uint32_t* tick;      // [kFoldSlots] runs parked so far
+    uint32_t* free;      // [kFoldSlots] stack of free slots
+    uint32_t* top;       // entries on the stack
+};
+__device__ __forceinline__ WaveBook wave_book(uint32_t* lds, uint32_t lane)
+{
+    WaveBook b; b.tick = lds; b.free = lds + kFoldSlots; b.top = lds + 2u * kFoldSlots;
+    b.tick[lane] = 0u; b.tick[64u + lane] = 0u;
+    b.free[lane] = lane; b.free[64u + lane] = 64u + lane;
+    if (lane == 0u) *b.top = kFoldSlots;
+    return b;
+}
 
 struct QueueState {
     uint32_t shard, shards_left, res_first, res_count;
-    uint32_t cur_slot;                    // slot of the group the reserve currently stands inside (kNoSlot: padding group)
     uint32_t grant_g0;                    // first group of the current grant
-    uint32_t grp_pxy, grp_seed;           // PER LANE: lane j holds pixel (x | y << 16, 0xFFFFFFFF = padding) and tea<4> seed of group grant_g0 + j
-    unsigned long long free0, free1;      // free fold slots 0..63, 64..127
+    uint32_t grp_pxy, grp_seed, grp_slot; // PER LANE: lane j holds pixel (x | y << 16, 0xFFFFFFFF = padding), tea<4> seed and fold slot of group grant_g0 + j
 };
 
 struct LanePixel {
@@ -67,17 +81,6 @@ struct LanePixel {
 };
 
 __device__ __forceinline__ uint32_t pixel_index(const RenderArgs& A, const LanePixel& lp) { return (lp.pxy >> 16) * A.width + (lp.pxy & 0xFFFFu); }
-
-__device__ __forceinline__ uint32_t alloc_slot(QueueState& q)
-{
-    if (q.free0 != 0ull) { const uint32_t s = (uint32_t)__ffsll((long long)q.free0) - 1u; q.free0 &= q.free0 - 1ull; return s; }
-    if (q.free1 != 0ull) { const uint32_t s = (uint32_t)__ffsll((long long)q.free1) - 1u; q.free1 &= q.free1 - 1ull; return 64u + s; }
-    return kNoSlot;
-}
-__device__ __forceinline__ void free_slot(QueueState& q, uint32_t s)
-{
-    if (s < 64u) q.free0 |= 1ull << s; else q.free1 |= 1ull << (s - 64u);
-}
 
 // n / d for a launch constant d by multiply-high and shifts (Granlund & Montgomery 1994, N = 32: exact for every
 // 32-bit n); capi.hip builds {mul, sh1, sh2} and checks them.  Integer division has no scalar instruction and costs
@@ -106,11 +109,11 @@ __device__ __forceinline__ void sample_pixel_fast(const RenderArgs& A, uint32_t 
 // in the kernel-argument segment would be a global load on the deal's critical path)
 template <bool STATS = false>
 __device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q, uint32_t lane, unsigned long long below, LanePixel& lp,
-                                             const uint32_t* lcg_skip, bool hold = false)
+                                             const uint32_t* lcg_skip, const WaveBook& book)
 {
     const uint32_t cs = A.chunk_shift, run_mask = (1u << cs) - 1u;
     const uint32_t fshift = A.sub_shift - cs, fmask = (1u << fshift) - 1u;      // group index = pixel slot << fshift | sub-frame
-    unsigned long long idle = vote(!lp.alive && !hold);
+    unsigned long long idle = vote(!lp.alive);
     while (idle != 0ull && (q.res_count != 0u || q.shards_left != 0u)) {
         if (q.res_count == 0u) {                                      // wave-uniform: fetch a grant
             const uint32_t leader = (uint32_t)__ffsll((long long)idle) - 1u;
@@ -146,10 +149,15 @@ __device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q,
                 const bool ok = (g << cs) < first + avail && x < A.width && y < A.height && f < A.n_frames;   // else: padding of the tile / batch grid
                 q.grp_pxy = ok ? (x | (y << 16)) : 0xFFFFFFFFu;
                 q.grp_seed = tea4(y * A.width + x, A.frame + f);
+                // fold slots for the grant's groups: the n-th real group takes the n-th entry from the top of the free stack
+                const unsigned long long okm = vote(ok);
+                const uint32_t top = (uint32_t)__builtin_amdgcn_readfirstlane((int)*book.top);
+                q.grp_slot = ok ? book.free[top - 1u - (uint32_t)popc(okm & below)] : kNoSlot;
+                if (lane == 0u) *book.top = top - (uint32_t)popc(okm);
             }
         }
         const uint32_t want = (uint32_t)popc(idle);
-        uint32_t take = want < q.res_count ? want : q.res_count;
+        const uint32_t take = want < q.res_count ? want : q.res_count;
         const uint32_t rank = (uint32_t)popc(idle & below);
         const uint32_t item = q.res_first + rank;
         if (cs == 0u) {
@@ -167,41 +175,25 @@ __device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q,
                 lp.new_path = true;
             }
         } else {
-            // Several runs per group.  The deal touches <= take / runs + 1 consecutive groups of the current grant (decoded when
-            // the grant was fetched); each gets its fold slot when its first run is dealt, and the lanes that drew one of its
-            // runs copy pixel and seed and skip the LCG ahead to their run.
-            const uint32_t g_first = q.res_first >> cs, g_last = (q.res_first + take - 1u) >> cs;
-            const uint32_t my_g = item >> cs;
+            // Several runs per group: a lane fetches pixel, seed and fold slot of its group from the lane that decoded it when
+            // the grant was taken, and skips the LCG ahead to its run.
             const uint32_t run = item & run_mask;
-            for (uint32_t g = g_first; g <= g_last; g++) {
-                const uint32_t f = g & fmask;
-                const uint32_t pxy = (uint32_t)__builtin_amdgcn_readlane((int)q.grp_pxy, (int)(g - q.grant_g0));
-                const uint32_t seed0 = (uint32_t)__builtin_amdgcn_readlane((int)q.grp_seed, (int)(g - q.grant_g0));
-                uint32_t sl;
-                if ((g << cs) < q.res_first) {
-                    sl = q.cur_slot;                                   // the group the previous deal stopped inside
-                } else {
-                    sl = kNoSlot;
-                    if (pxy != 0xFFFFFFFFu) {
-                        sl = alloc_slot(q);
-                        if (sl == kNoSlot) { take = (g << cs) - q.res_first; break; }   // cannot happen (see above); deal the rest next round
-                    }
-                    q.cur_slot = sl;
-                }
-                if (sl != kNoSlot && !lp.alive && rank < take && my_g == g) {
-                    lp.pxy = pxy;
-                    lp.tag = (f << cs) | run | (sl << 16);
-                    lp.seed = lcg_skip[2u * run] * seed0 + lcg_skip[2u * run + 1u];     // skip the jitter draws of the samples before this run (2 per sample)
-                    lp.result = mk(0.0f);
-                    lp.samples_left = A.chunk_spp;
-                    lp.alive = true;
-                    lp.new_path = true;
-                }
+            const int src = (int)(((item >> cs) - q.grant_g0) << 2);           // ds_bpermute takes a byte index
+            const uint32_t pxy = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)q.grp_pxy);
+            const uint32_t seed0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)q.grp_seed);
+            const uint32_t sl = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)q.grp_slot);
+            if (!lp.alive && rank < take && pxy != 0xFFFFFFFFu) {
+                lp.pxy = pxy;
+                lp.tag = (((item >> cs) & fmask) << cs) | run | (sl << 16);
+                lp.seed = lcg_skip[2u * run] * seed0 + lcg_skip[2u * run + 1u];     // skip the jitter draws of the samples before this run (2 per sample)
+                lp.result = mk(0.0f);
+                lp.samples_left = A.chunk_spp;
+                lp.alive = true;
+                lp.new_path = true;
             }
         }
         q.res_first += take; q.res_count -= take;
-        if (take == 0u) break;
-        idle = vote(!lp.alive && !hold);          // lanes that drew a padding item try again
+        idle = vote(!lp.alive);          // lanes that drew a padding item try again
     }
 }
 
@@ -241,13 +233,11 @@ __device__ __forceinline__ void load4_coherent(const float4* p, v4f_t& a, v4f_t&
 }
 
 // Lanes with `finished` set have completed their run of samples.  One run per pixel: write.  Several: park the partial
-// sum in the group's fold slot, bump the ticket, and let the lane that completes the group add the runs in order.
-// tick_lo / tick_hi: lane s holds the ticket of slot s / 64 + s.  scratch: this wave's kFoldSlots << chunk_shift float4.
-__device__ __forceinline__ void finish_runs(const RenderArgs& A, QueueState& q, const LanePixel& lp, bool finished, uint32_t lane,
-                                            uint32_t& tick_lo, uint32_t& tick_hi, float4* __restrict__ scratch)
+// sum in the group's fold slot, bump the slot's ticket, and the lane that completes the group adds the runs in order.
+// scratch: this wave's kFoldSlots << chunk_shift float4.
+__device__ __forceinline__ void finish_runs(const RenderArgs& A, const LanePixel& lp, bool finished, const WaveBook& book, float4* __restrict__ scratch)
 {
-    const unsigned long long fin = vote(finished);
-    if (fin == 0ull) return;
+    if (vote(finished) == 0ull) return;
     const uint32_t cs = A.chunk_shift, runs = 1u << cs;
     const uint32_t sub = lp.tag & 0xFFFFu;
     if (cs == 0u) {
@@ -256,24 +246,17 @@ __device__ __forceinline__ void finish_runs(const RenderArgs& A, QueueState& q, 
     }
     const uint32_t slot = lp.tag >> 16;
     float4* group = scratch + ((size_t)slot << cs);
-    if (finished) group[sub & (runs - 1u)] = make_float4(lp.result.x, lp.result.y, lp.result.z, 0.0f);
-    unsigned long long folders = 0ull;
-    for (unsigned long long m = fin; m != 0ull; m &= m - 1ull) {          // wave-uniform: one turn per finishing lane
-        const int l = __ffsll((long long)m) - 1;
-        const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)slot, l);
-        const bool hi = sl >= 64u;
-        const int tl = (int)(sl & 63u);
-        uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)(hi ? tick_hi : tick_lo), tl) + 1u;
-        if (c == runs) { folders |= 1ull << l; c = 0u; free_slot(q, sl); }
-        if (hi) tick_hi = (int)lane == tl ? c : tick_hi;
-        else    tick_lo = (int)lane == tl ? c : tick_lo;
+    bool folder = false;
+    if (finished) {
+        group[sub & (runs - 1u)] = make_float4(lp.result.x, lp.result.y, lp.result.z, 0.0f);
+        folder = atomicAdd(&book.tick[slot], 1u) == runs - 1u;       // LDS: lanes of one group that finish together get distinct counts
     }
-    if (folders == 0ull) return;
+    if (vote(folder) == 0ull) return;
     // the partial sums were stored by lanes of this wave through this CU's L1: wait for the stores, then read them back
     // past the L1 (agent-scope loads), whatever lines an earlier use of the slot left there
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0) only
-    if ((folders >> lane) & 1ull) {
+    if (folder) {
         // the loads of four runs in flight at once (one latency per four runs, not one per run)
         f3 sum = mk(0.0f);
         if (runs == 2u) {
@@ -292,6 +275,8 @@ __device__ __forceinline__ void finish_runs(const RenderArgs& A, QueueState& q, 
             }
         }
         write_frame_sum(A, pixel_index(A, lp), sub >> cs, sum);
+        book.tick[slot] = 0u;
+        book.free[atomicAdd(book.top, 1u)] = slot;                   // back on the free stack
     }
 }
 
@@ -357,6 +342,7 @@ k_render(const RenderArgsBox B)
     st.base = lds_dyn + wave * (A.stack_entries * 64u) + lane;
     uint32_t* const lcg_skip = lds_dyn + (kRenderThreads / 64) * (A.stack_entries * 64u);      // 64 dwords behind the stacks
     if (threadIdx.x < 32u) { lcg_skip[2u * threadIdx.x] = A.lcg_mul[threadIdx.x]; lcg_skip[2u * threadIdx.x + 1u] = A.lcg_add[threadIdx.x]; }
+    const WaveBook book = wave_book(lcg_skip + 64u + wave * kBookDwords, lane);
     __syncthreads();
     const DeviceScene sc = A.scene;
     const auto late = [&]() -> const RenderArgs& { return A; };
@@ -364,9 +350,8 @@ k_render(const RenderArgsBox B)
     const float fw = (float)(int)A.width, fh = (float)(int)A.height;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-    QueueState q; q.shard = xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.cur_slot = kNoSlot; q.grant_g0 = 0; q.grp_pxy = 0xFFFFFFFFu; q.grp_seed = 0; q.free0 = ~0ull; q.free1 = ~0ull;
+    QueueState q; q.shard = xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.grant_g0 = 0; q.grp_pxy = 0xFFFFFFFFu; q.grp_seed = 0; q.grp_slot = kNoSlot;
     unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0;
-    uint32_t tick_lo = 0u, tick_hi = 0u;
     float4* const scratch = A.wave_scratch + (size_t)(blockIdx.x * (kRenderThreads / 64) + wave) * ((size_t)kFoldSlots << A.chunk_shift);
 
     LanePixel lp; lp.alive = false; lp.new_path = false; lp.pxy = lp.seed = lp.samples_left = lp.tag = 0; lp.result = mk(0.0f);
@@ -375,7 +360,7 @@ k_render(const RenderArgsBox B)
     f3 org = mk(0.0f), dir = mk(0.0f, 0.0f, 1.0f), att = mk(1.0f);
 
     for (;;) {
-        refill_lanes(A, q, lane, below, lp, lcg_skip);
+        refill_lanes(A, q, lane, below, lp, lcg_skip, book);
         const unsigned long long live = vote(lp.alive);
         if (live == 0ull) { if (q.shards_left == 0u && q.res_count == 0u) break; else continue; }
 
@@ -430,7 +415,7 @@ k_render(const RenderArgsBox B)
         }
         n_paths += (unsigned long long)popc(vote(end));
         n_pixels += (unsigned long long)popc(vote(finished));
-        finish_runs(A, q, lp, finished, lane, tick_lo, tick_hi, scratch);
+        finish_runs(A, lp, finished, book, scratch);
     }
     if (lane == 0) {
         atomicAdd(&A.counters[0], n_radiance);
@@ -520,12 +505,12 @@ k_render_pw(const RenderArgsBox B)
     // LCG skip-ahead table behind the stacks (and behind the LDS-staged nodes of NODE_FMT 2)
     uint32_t* const lcg_skip = lds_dyn + (THREADS / 64) * (A.stack_entries * 64u) + (NODE_FMT == 2 ? A.n_lds_nodes * 8u : 0u);
     if (threadIdx.x < 32u) { lcg_skip[2u * threadIdx.x] = A.lcg_mul[threadIdx.x]; lcg_skip[2u * threadIdx.x + 1u] = A.lcg_add[threadIdx.x]; }
+    const WaveBook book = wave_book(lcg_skip + 64u + wave * kBookDwords, lane);
     __syncthreads();
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int root = sc.n_tris ? 0 : kSentinel;
 
-    QueueState q; q.shard = xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.cur_slot = kNoSlot; q.grant_g0 = 0; q.grp_pxy = 0xFFFFFFFFu; q.grp_seed = 0; q.free0 = ~0ull; q.free1 = ~0ull;
-    uint32_t tick_lo = 0u, tick_hi = 0u;
+    QueueState q; q.shard = xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.grant_g0 = 0; q.grp_pxy = 0xFFFFFFFFu; q.grp_seed = 0; q.grp_slot = kNoSlot;
     float4* const scratch = A.wave_scratch + (size_t)(blockIdx.x * (THREADS / 64) + wave) * ((size_t)kFoldSlots << A.chunk_shift);
     unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0;
     unsigned long long n_steps = 0, n_lane_steps = 0, n_rounds = 0, n_lane_rounds = 0;
@@ -604,10 +589,10 @@ k_render_pw(const RenderArgsBox B)
         fin_pending = false;
         n_pixels += (unsigned long long)popc(vote(finished));
         if (STATS) t_mark = __builtin_amdgcn_s_memrealtime();
-        finish_runs(A, q, lp, finished, lane, tick_lo, tick_hi, scratch);     // before the refill overwrites the lanes' items
+        finish_runs(A, lp, finished, book, scratch);     // before the refill overwrites the lanes' items
         if (STATS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); t_finish += now - t_mark; t_mark = now; }
 
-        refill_lanes<STATS>(A, q, lane, below, lp, lcg_skip);
+        refill_lanes<STATS>(A, q, lane, below, lp, lcg_skip, book);
         if (STATS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); t_refill += now - t_mark; t_mark = now; }
         if (STATS && t_drain == 0ull && q.shards_left == 0u && q.res_count == 0u) t_drain = __builtin_amdgcn_s_memrealtime();
 
@@ -1332,7 +1317,7 @@ int render_variant_threads(int v) { return (v >= 0 && v < render_variant_count()
 
 static size_t variant_lds(const VariantDesc& d, uint32_t stack_entries, uint32_t n_nodes)
 {
-    size_t lds = (size_t)(d.threads / 64) * stack_entries * 256u + 256u;      // lane stacks + the LCG skip-ahead table
+    size_t lds = (size_t)(d.threads / 64) * (stack_entries * 256u + kBookDwords * 4u) + 256u;      // lane stacks, fold bookkeeping, LCG skip-ahead table
     if (d.node_fmt == 2) lds += (size_t)n_nodes * sizeof(QNode);
     return lds;
 }
