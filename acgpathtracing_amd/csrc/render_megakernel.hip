@@ -50,18 +50,22 @@ extern __shared__ uint32_t lds_dyn[];
 // in flight + one grant (<= 48 groups), slots 128.
 constexpr uint32_t kFoldSlots = 128u;
 constexpr uint32_t kNoSlot = 0xFFu;
-constexpr uint32_t kBookDwords = 2u * kFoldSlots + 8u;        // per wave in LDS: tickets, free-slot stack, its height (+ padding)
+constexpr uint32_t kBookDwords = kFoldSlots / 2u + 2u;        // per wave in LDS: tickets and free-slot stack (a byte each), the stack's height
 
 struct WaveBook {
-    uint32_t* tick;      // [kFoldSlots] runs parked so far
-    uint32_t* free;      // [kFoldSlots] stack of free slots
+    uint32_t* tick;      // [kFoldSlots / 4] runs parked so far, one byte per slot (<= 32 runs)
+    uint8_t*  free;      // [kFoldSlots] stack of free slots
     uint32_t* top;       // entries on the stack
+    // park one more run in `slot`; returns how many were parked before (ds_add_rtn_u32 on the byte's dword)
+    __device__ __forceinline__ uint32_t bump(uint32_t slot) const
+    { return (atomicAdd(&tick[slot >> 2], 1u << (8u * (slot & 3u))) >> (8u * (slot & 3u))) & 0xFFu; }
+    __device__ __forceinline__ void clear(uint32_t slot) const { atomicAnd(&tick[slot >> 2], ~(0xFFu << (8u * (slot & 3u)))); }
 };
 __device__ __forceinline__ WaveBook wave_book(uint32_t* lds, uint32_t lane)
 {
-    WaveBook b; b.tick = lds; b.free = lds + kFoldSlots; b.top = lds + 2u * kFoldSlots;
-    b.tick[lane] = 0u; b.tick[64u + lane] = 0u;
-    b.free[lane] = lane; b.free[64u + lane] = 64u + lane;
+    WaveBook b; b.tick = lds; b.free = (uint8_t*)(lds + kFoldSlots / 4u); b.top = lds + kFoldSlots / 2u;
+    if (lane < kFoldSlots / 4u) b.tick[lane] = 0u;
+    b.free[lane] = (uint8_t)lane; b.free[64u + lane] = (uint8_t)(64u + lane);
     if (lane == 0u) *b.top = kFoldSlots;
     return b;
 }
@@ -138,8 +142,8 @@ __device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q,
             if (avail < req) { q.shard = (q.shard + 1u) & 7u; q.shards_left--; }   // shard drained: steal from the next
             q.res_first = first; q.res_count = avail;
             if (avail == 0u) continue;
-            if (cs != 0u) {
-                // decode the grant's groups side by side, one per lane (<= 48 of them): tile order -> pixel, tea<4> seed (:721).
+            {
+                // decode the grant's groups side by side, one per lane (<= 64 of them): tile order -> pixel, tea<4> seed (:721).
                 // Once per grant instead of one serial tea<4> chain per group on the deal's critical path.
                 q.grant_g0 = first >> cs;
                 const uint32_t g = q.grant_g0 + lane;
@@ -149,34 +153,22 @@ __device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q,
                 const bool ok = (g << cs) < first + avail && x < A.width && y < A.height && f < A.n_frames;   // else: padding of the tile / batch grid
                 q.grp_pxy = ok ? (x | (y << 16)) : 0xFFFFFFFFu;
                 q.grp_seed = tea4(y * A.width + x, A.frame + f);
-                // fold slots for the grant's groups: the n-th real group takes the n-th entry from the top of the free stack
-                const unsigned long long okm = vote(ok);
-                const uint32_t top = (uint32_t)__builtin_amdgcn_readfirstlane((int)*book.top);
-                q.grp_slot = ok ? book.free[top - 1u - (uint32_t)popc(okm & below)] : kNoSlot;
-                if (lane == 0u) *book.top = top - (uint32_t)popc(okm);
+                q.grp_slot = kNoSlot;
+                if (cs != 0u) {   // fold slots for the grant's groups: the n-th real group takes the n-th entry from the top of the free stack
+                    const unsigned long long okm = vote(ok);
+                    const uint32_t top = (uint32_t)__builtin_amdgcn_readfirstlane((int)*book.top);
+                    if (ok) q.grp_slot = (uint32_t)book.free[top - 1u - (uint32_t)popc(okm & below)];
+                    if (lane == 0u) *book.top = top - (uint32_t)popc(okm);
+                }
             }
         }
         const uint32_t want = (uint32_t)popc(idle);
         const uint32_t take = want < q.res_count ? want : q.res_count;
         const uint32_t rank = (uint32_t)popc(idle & below);
         const uint32_t item = q.res_first + rank;
-        if (cs == 0u) {
-            // one run per (pixel, sub-frame): every lane decodes its own item
-            uint32_t x, y;
-            sample_pixel_fast(A, item >> A.sub_shift, x, y);
-            const uint32_t f = item & fmask;
-            if (!lp.alive && rank < take && x < A.width && y < A.height && f < A.n_frames) {   // else: padding of the tile / batch grid
-                lp.pxy = x | (y << 16);
-                lp.tag = f | (kNoSlot << 16);
-                lp.seed = tea4(y * A.width + x, A.frame + f);                                 // :721
-                lp.result = mk(0.0f);
-                lp.samples_left = A.chunk_spp;
-                lp.alive = true;
-                lp.new_path = true;
-            }
-        } else {
-            // Several runs per group: a lane fetches pixel, seed and fold slot of its group from the lane that decoded it when
-            // the grant was taken, and skips the LCG ahead to its run.
+        {
+            // a lane fetches pixel, seed and fold slot of its group from the lane that decoded it when the grant was taken, and
+            // skips the LCG ahead to its run (one run per group: a skip of zero steps, no slot)
             const uint32_t run = item & run_mask;
             const int src = (int)(((item >> cs) - q.grant_g0) << 2);           // ds_bpermute takes a byte index
             const uint32_t pxy = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)q.grp_pxy);
@@ -249,7 +241,7 @@ __device__ __forceinline__ void finish_runs(const RenderArgs& A, const LanePixel
     bool folder = false;
     if (finished) {
         group[sub & (runs - 1u)] = make_float4(lp.result.x, lp.result.y, lp.result.z, 0.0f);
-        folder = atomicAdd(&book.tick[slot], 1u) == runs - 1u;       // LDS: lanes of one group that finish together get distinct counts
+        folder = book.bump(slot) == runs - 1u;                       // LDS: lanes of one group that finish together get distinct counts
     }
     if (vote(folder) == 0ull) return;
     // the partial sums were stored by lanes of this wave through this CU's L1: wait for the stores, then read them back
@@ -275,8 +267,8 @@ __device__ __forceinline__ void finish_runs(const RenderArgs& A, const LanePixel
             }
         }
         write_frame_sum(A, pixel_index(A, lp), sub >> cs, sum);
-        book.tick[slot] = 0u;
-        book.free[atomicAdd(book.top, 1u)] = slot;                   // back on the free stack
+        book.clear(slot);
+        book.free[atomicAdd(book.top, 1u)] = (uint8_t)slot;          // back on the free stack
     }
 }
 
