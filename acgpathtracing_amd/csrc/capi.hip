@@ -123,7 +123,10 @@ static int pick_variant(const pt_ctx* c)
 {
     const bool half_ok = c->bvh.half_area_ratio <= ptd::kHalfAreaLimit;
     const bool large = c->bvh.n_tris > ptd::kLargeSceneTris;
-    return half_ok ? (large ? ptd::kVariantF16Large : ptd::kVariantF16) : (large ? ptd::kVariantF32Large : ptd::kVariantF32);
+    if (!half_ok) return large ? ptd::kVariantF32Large : ptd::kVariantF32;
+    int w5_blocks = 0;      // do five workgroups of the five-wave kernel fit a CU with this tree's stack depth?
+    if (ptd::render_occupancy(ptd::kVariantF16W5, c->stack_entries, c->bvh.n_nodes, &w5_blocks) == hipSuccess && w5_blocks >= 5) return ptd::kVariantF16W5;
+    return ptd::kVariantF16;
 }
 
 // dwords per lane: one push per internal node on a root-to-leaf path at most (two-child tree), or one
@@ -174,8 +177,8 @@ PT_API int pt_set_scene(pt_ctx* c, const float* verts_xyzw, size_t n_verts, cons
         CK(c, hipMemcpy(c->d_mats, mats, n_mats * sizeof(pt_material), hipMemcpyHostToDevice));
     }
     c->n_mats = (uint32_t)n_mats;
-    if (c->variant_auto) c->variant = pick_variant(c);
-    if (int rc = size_stack(c)) return rc;
+    if (int rc = size_stack(c)) return rc;              // stack depth first: the choice below depends on it
+    if (c->variant_auto) { c->variant = pick_variant(c); if (int rc = size_stack(c)) return rc; }
     if (ptd::render_variant_node_format(c->variant) == 3) { if (int rc = ensure_wide(c)) return rc; }
     c->scene_serial++;
     return 0;

@@ -9,11 +9,12 @@ constexpr int kRenderThreads = 256;   // 4 waves per workgroup (segment-synchron
 constexpr uint32_t kRenderFoldSlots = 128;  // fold slots per wave (render_megakernel.hip kFoldSlots)
 constexpr uint32_t kMaxTimedWaves = 16384;   // stats variants stamp start / queue-empty / end per wave behind the 8 counters
 // Variant indices of the product library (render_megakernel.hip kVariants).  pt_set_scene picks one per scene unless
-// pt_set_tuning named one: fp16 nodes when the fp16 planes cost less than kHalfAreaLimit in summed child-box area (every
-// Cornell-class scene), fp32 nodes otherwise; above kLargeSceneTris the shape with triangle rounds at 8 lanes.
+// pt_set_tuning named one.  fp16 nodes when the fp16 planes cost less than kHalfAreaLimit in summed child-box area (every
+// scene tried so far): the five-waves-per-SIMD kernel when five workgroups' lane stacks fit a CU's LDS (trees up to ~28
+// levels), else the four-wave sign-rotated one.  fp32 nodes otherwise, with triangle rounds at 8 lanes above kLargeSceneTris.
 constexpr int kVariantSync = 0, kVariantF32 = 1, kVariantF32Stats = 2, kVariantF32Large = 3, kVariantFastMath = 4;
-constexpr int kVariantF16 = 5, kVariantF16Stats = 6, kVariantF16Large = 5;   // one shape serves both sizes (profiles/r02_sweep_*)
-constexpr int kDefaultVariant = kVariantF16;
+constexpr int kVariantF16 = 5, kVariantF16Stats = 6, kVariantF16W5 = 7;
+constexpr int kDefaultVariant = kVariantF16W5;
 constexpr uint32_t kLargeSceneTris = 100000;
 constexpr float kHalfAreaLimit = 1.05f;
 

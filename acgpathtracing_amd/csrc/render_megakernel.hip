@@ -1261,6 +1261,7 @@ static const VariantDesc kVariants[] = {
     {k_render_pw<48, 12, 0, 256, 4, false, 3, 1>, 256, 0, "FAST-MATH hardware sin/cos + algebraic acos in the cosine-weighted sampler (opt-in; other bits than the default)"},
     {k_render_pw<44, 16, 8, 256, 4, false, 0, 3, 2>, 256, 8, "pw K44 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes, w4, three visits and two triangle tests per loop trip"},
     {k_render_pw<44, 16, 8, 256, 4, true, 0, 3, 2>, 256, 8, "pw K44 L16 fp16 sign-rotated nodes + scheduler stats"},
+    {k_render_pw<44, 16, 7, 256, 5, false, 0, 3, 2>, 256, 7, "pw K44 L16 fp16 nodes (32 B), v_fma_mix planes with per-axis min / max, FIVE waves per SIMD (96 registers), three visits and two triangle tests per loop trip"},
 #ifdef ACGPT_EXPERIMENTS
     {k_render_pw<40, 8, 0, 256, 4, false, 0, 1>, 256, 0, "pw K40 L8 fp32 w4, register stack top"},
     {k_render_pw<48, 8, 0, 256, 4, false>, 256, 0, "pw K48 L8 fp32 w4, LDS-only stack"},
@@ -1300,6 +1301,17 @@ static const VariantDesc kVariants[] = {
     {k_render_pw<44, 24, 7, 256, 4, false, 0, 2, 2>, 256, 7, "pw K44 L24 fp16 V2 T2"},
     {k_render_pw<44, 16, 7, 256, 4, false, 0, 3, 2>, 256, 7, "pw K44 L16 fp16 V3 T2"},
     {k_render_pw<44, 16, 7, 256, 5, false, 0, 2, 2>, 256, 7, "pw K44 L16 fp16 V2 T2 w5"},
+    {k_render_pw<40, 16, 7, 256, 5, false, 0, 2, 2>, 256, 7, "pw K40 L16 fp16 V2 T2 w5"},
+    {k_render_pw<48, 16, 7, 256, 5, false, 0, 2, 2>, 256, 7, "pw K48 L16 fp16 V2 T2 w5"},
+    {k_render_pw<44, 12, 7, 256, 5, false, 0, 2, 2>, 256, 7, "pw K44 L12 fp16 V2 T2 w5"},
+    {k_render_pw<44, 20, 7, 256, 5, false, 0, 2, 2>, 256, 7, "pw K44 L20 fp16 V2 T2 w5"},
+    {k_render_pw<44, 16, 7, 256, 5, false, 0, 2, 1>, 256, 7, "pw K44 L16 fp16 V2 T1 w5"},
+    {k_render_pw<44, 16, 7, 256, 5, false, 0, 2, 3>, 256, 7, "pw K44 L16 fp16 V2 T3 w5"},
+    {k_render_pw<44, 16, 7, 256, 6, false, 0, 2, 2>, 256, 7, "pw K44 L16 fp16 V2 T2 w6"},
+    {k_render_pw<44, 16, 0, 256, 5, false, 0, 2, 2>, 256, 0, "pw K44 L16 fp32 V2 T2 w5"},
+    {k_render_pw<44, 16, 6, 256, 5, false, 0, 2, 2>, 256, 0, "pw K44 L16 fp32 centre / half-extent V2 T2 w5"},
+    {k_render_pw<48, 16, 8, 256, 5, false, 0, 2, 2>, 256, 8, "pw K48 L16 fp16 sign-rotated V2 T2 w5"},
+    {k_render_pw<40, 16, 8, 256, 5, false, 0, 2, 2>, 256, 8, "pw K40 L16 fp16 sign-rotated V2 T2 w5"},
 #endif
 };
 int render_variant_count() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
