@@ -31,6 +31,10 @@ struct pt_ctx {
     ptd::LbvhResult bvh;
     pt_material* d_mats = nullptr;
     uint32_t n_mats = 0;
+    float4* d_lights = nullptr;               // emissive triangles of the scene (light mode 1), 5 float4 each
+    uint32_t n_lights = 0;
+    float light_area = 0.0f;
+    int light_mode = 0;                       // 0 the reference's estimator, 1 scene lights + MIS (pt_set_light_mode)
     uint32_t stack_entries = 8;
     int blocks_per_cu = 0;        // from the occupancy query for the current stack size
     int tune_blocks_per_cu = 0;   // user override
@@ -101,6 +105,8 @@ static void free_scene(pt_ctx* c)
     ptd::free_lbvh(c->bvh);
     if (c->d_mats) { (void)hipFree(c->d_mats); c->d_mats = nullptr; }
     c->n_mats = 0;
+    if (c->d_lights) { (void)hipFree(c->d_lights); c->d_lights = nullptr; }
+    c->n_lights = 0; c->light_area = 0.0f;
 }
 
 PT_API void pt_destroy(pt_ctx* c)
@@ -177,6 +183,34 @@ PT_API int pt_set_scene(pt_ctx* c, const float* verts_xyzw, size_t n_verts, cons
         CK(c, hipMemcpy(c->d_mats, mats, n_mats * sizeof(pt_material), hipMemcpyHostToDevice));
     }
     c->n_mats = (uint32_t)n_mats;
+    {   // light mode 1: every triangle with an emissive material, in triangle order; same fp32 operations as the oracle's
+        // orc_scene_create (edges by one subtraction, cross / length / normalize of sutil/vec_math.h:533-549, running area sum)
+        std::vector<float4> lights;
+        float run = 0.0f;
+        for (size_t i = 0; i < n_tris; i++) {
+            const pt_float3 ke = mats[mat_ids[i]].emission;
+            if (!(sqrtf(ke.x * ke.x + ke.y * ke.y + ke.z * ke.z) > 0.0f)) continue;
+            const float* a = verts_xyzw + 4 * (size_t)idx[3 * i], *b = verts_xyzw + 4 * (size_t)idx[3 * i + 1], *cc = verts_xyzw + 4 * (size_t)idx[3 * i + 2];
+            const float e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {cc[0] - a[0], cc[1] - a[1], cc[2] - a[2]};
+            const float cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+            const float len = sqrtf(cx * cx + cy * cy + cz * cz);
+            const float area = 0.5f * len;
+            if (!(area > 0.0f)) continue;
+            const float inv = 1.0f / len;
+            run += area;
+            lights.push_back(make_float4(a[0], a[1], a[2], area));
+            lights.push_back(make_float4(e1[0], e1[1], e1[2], run));
+            lights.push_back(make_float4(e2[0], e2[1], e2[2], 0.0f));
+            lights.push_back(make_float4(cx * inv, cy * inv, cz * inv, 0.0f));
+            lights.push_back(make_float4(ke.x, ke.y, ke.z, 0.0f));
+        }
+        if (!lights.empty()) {
+            CK(c, hipMalloc((void**)&c->d_lights, lights.size() * sizeof(float4)));
+            CK(c, hipMemcpy(c->d_lights, lights.data(), lights.size() * sizeof(float4), hipMemcpyHostToDevice));
+        }
+        c->n_lights = (uint32_t)(lights.size() / 5);
+        c->light_area = run;
+    }
     if (int rc = size_stack(c)) return rc;              // stack depth first: the choice below depends on it
     if (c->variant_auto) { c->variant = pick_variant(c); if (int rc = size_stack(c)) return rc; }
     if (ptd::render_variant_node_format(c->variant) == 3) { if (int rc = ensure_wide(c)) return rc; }
@@ -212,6 +246,14 @@ PT_API int pt_set_partition(pt_ctx* c, int rank, int world)
     if (!c) return fail(nullptr, "pt_set_partition: null context");
     if (world < 1 || rank < 0 || rank >= world) return fail(c, "pt_set_partition: need 0 <= rank < world");
     c->rank = rank; c->world = world;
+    return 0;
+}
+
+PT_API int pt_set_light_mode(pt_ctx* c, int mode)
+{
+    if (!c) return fail(nullptr, "pt_set_light_mode: null context");
+    if (mode != 0 && mode != 1) return fail(c, "pt_set_light_mode: 0 = the reference's estimator (hard-coded rectangle, PathTracerMain.cpp:154-158), 1 = scene lights + MIS");
+    c->light_mode = mode;
     return 0;
 }
 
@@ -263,6 +305,7 @@ static ptd::DeviceScene device_scene(pt_ctx* c)
     ptd::DeviceScene sc;
     sc.nodes = c->bvh.nodes; sc.qnodes = c->bvh.qnodes; sc.cnodes = c->bvh.cnodes; sc.hnodes = c->bvh.hnodes; sc.hspace = c->bvh.hspace; sc.grid = c->bvh.grid; sc.tris = c->bvh.tris; sc.wrecs = c->bvh.wrecs; sc.mats = c->d_mats;
     sc.n_tris = c->bvh.n_tris; sc.n_mats = c->n_mats;
+    sc.lights = c->d_lights; sc.n_lights = c->n_lights; sc.light_area = c->light_area;
     return sc;
 }
 
@@ -415,15 +458,19 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
     a.stack_entries = c->stack_entries;
     a.n_lds_nodes = c->bvh.n_nodes;
 
-    int bpc = c->tune_blocks_per_cu > 0 ? c->tune_blocks_per_cu : c->blocks_per_cu;
-    if (bpc < 1) {   // no scene yet: empty world, every ray misses
-        CK(c, ptd::render_occupancy(c->variant, c->stack_entries, c->bvh.n_nodes, &c->blocks_per_cu));
-        bpc = c->blocks_per_cu > 0 ? c->blocks_per_cu : 1;
+    // light mode 1 has its own kernel (the estimator differs); every other choice is c->variant
+    const int variant = c->light_mode == 1 ? ptd::kVariantLights : c->variant;
+    int fit = c->blocks_per_cu;
+    if (variant != c->variant || fit < 1) {   // (fit < 1: no scene yet — empty world, every ray misses)
+        CK(c, ptd::render_occupancy(variant, c->stack_entries, c->bvh.n_nodes, &fit));
+        if (variant == c->variant) c->blocks_per_cu = fit;
+        if (fit < 1) fit = 1;
     }
-    if (bpc > c->blocks_per_cu && c->blocks_per_cu > 0) bpc = c->blocks_per_cu;
+    int bpc = c->tune_blocks_per_cu > 0 ? c->tune_blocks_per_cu : fit;
+    if (bpc > fit) bpc = fit;
     uint32_t grid = (uint32_t)c->n_cus * (uint32_t)bpc;
     const uint32_t waves_needed = (a.total_samples + 63u) / 64u;
-    const uint32_t wpb = (uint32_t)ptd::render_variant_threads(c->variant) / 64u;
+    const uint32_t wpb = (uint32_t)ptd::render_variant_threads(variant) / 64u;
     const uint32_t blocks_needed = (waves_needed + wpb - 1) / wpb;
     if (grid > blocks_needed) grid = blocks_needed;
     if (grid < 1) grid = 1;
@@ -441,7 +488,7 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
     CK(c, hipMemsetAsync(c->d_queue, 0, 8 * sizeof(uint32_t), c->stream));
     CK(c, hipMemsetAsync(c->d_counters, 0, (8 + 3 * (size_t)ptd::kMaxTimedWaves + 2056) * sizeof(unsigned long long), c->stream));
     CK(c, hipEventRecord(c->ev0, c->stream));
-    CK(c, ptd::launch_render(c->variant, a, grid, c->stream));
+    CK(c, ptd::launch_render(variant, a, grid, c->stream));
     CK(c, hipEventRecord(c->ev1, c->stream));
     CK(c, ptd::launch_finalize(a, c->stream));
     unsigned long long h[8];
@@ -459,7 +506,7 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
     c->stats.shade_wave_rounds = h[6];
     c->stats.shade_lane_rounds = h[7];
     c->stats.grid_blocks = grid;
-    c->stats.variant = (uint32_t)c->variant;
+    c->stats.variant = (uint32_t)variant;
     c->stats.kernel_ms = ms;
     c->stats.launch_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return 0;

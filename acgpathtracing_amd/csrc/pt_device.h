@@ -76,6 +76,11 @@ struct DeviceScene {
     const pt_material* mats;
     uint32_t n_tris;
     uint32_t n_mats;
+    // light mode 1 (pt_set_light_mode): the scene's emissive triangles, 5 float4 each:
+    //   {v0.xyz, area} {e1.xyz, cdf} {e2.xyz, -} {n.xyz, -} {Ke.xyz, -}; cdf = running sum of the areas, light_area = its last value
+    const float4* lights;
+    uint32_t n_lights;
+    float light_area;
 };
 
 constexpr int   kSentinel  = 0x7FFFFFFF;   // stack bottom marker (never a valid node index)

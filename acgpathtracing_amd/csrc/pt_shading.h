@@ -232,4 +232,113 @@ __device__ __forceinline__ bool shade_hit(const DeviceScene& sc, Late late, cons
     return want_shadow;
 }
 
+// ---- light mode 1 (pt_set_light_mode; NOT the reference's estimator) ----------------------
+// Emissive triangles of the scene as the area light, next-event estimation and BSDF-sampled emitter hits combined with
+// the power heuristic, uniform hemisphere sampling with its 2 cos weight, emitters without the Kd quirks.  Same draws in
+// the same order as mode 0.  Operation for operation the twin of closesthit_scene_lights() in oracle/oracle_pt.cpp.
+// Out: pd.radiance = what this segment adds to the pixel, already times the throughput — at once for an emitter hit
+// (pd.done), or, when the function returns true, only if the shadow ray (P, L, 0.01, Ldist - 0.01) is unoccluded.
+// att becomes the throughput of the continuation; prev_pdf the solid-angle pdf of the sampled direction where a
+// light sample was taken (0 elsewhere: a later emitter hit then counts in full).
+template <typename Late>
+__device__ __forceinline__ bool shade_hit_lights(const DeviceScene& sc, Late late, const f3& org, const f3& dir,
+                                                 float t_hit, int slot, int depth, uint32_t& pseed, f3& att, float& prev_pdf,
+                                                 Pending& pd, f3& P, f3& L, float& Ldist)
+{
+    const TriRecord* tp = sc.tris + slot;
+    const float4 r0 = tp->r0, r1 = tp->r1, r2 = tp->r2;
+    const pt_material* mp = sc.mats + __float_as_uint(r2.z);
+    const f3 Kd = mk(mp->diffuse), Ke = mk(mp->emission);
+    const int bsdf = mp->bsdfType;
+    const f3 N0 = normalize(cross(mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x)));
+    const f3 N = faceforward(N0, -dir, N0);
+    P = org + t_hit * dir;
+    const auto& La = late();
+    const bool useDL = La.useDL != 0u && sc.n_lights != 0u;
+    const bool useIS = La.useIS != 0u;
+    const float area_total = sc.light_area;
+    uint32_t s = pseed;
+    pd.radiance = mk(0.0f); pd.weight = 0.0f;
+    pd.nxt_org = org; pd.nxt_dir = dir;
+    if (length(Ke) > 0.0f) {
+        float w = 1.0f;
+        if (depth > 0 && prev_pdf > 0.0f) {
+            const float cos_l = fabsf(dot(N0, dir));
+            const float p_l = (t_hit * t_hit) / (area_total * cos_l);
+            w = cos_l > 0.0f ? (prev_pdf * prev_pdf) / (prev_pdf * prev_pdf + p_l * p_l) : 1.0f;
+        }
+        pd.radiance = att * Ke * w;
+        if (bsdf == PT_BSDF_REFRACTION) (void)rnd(s); else { (void)rnd(s); (void)rnd(s); }
+        (void)rnd(s); (void)rnd(s);
+        pseed = s;
+        pd.done = true;
+        return false;
+    }
+    pd.done = false;
+    const f3 att_in = att;
+    float bsdf_pdf = 0.0f;
+    if (bsdf == PT_BSDF_DIFFUSE) {
+        const float z1 = rnd(s);
+        const float z2 = rnd(s);
+        f3 w_in = useIS ? cosine_sample_hemisphere(z1, z2) : uniform_sample_hemisphere(z1, z2);
+        const float cos_out = w_in.z;
+        onb_transform(N, w_in);
+        pd.nxt_dir = w_in;
+        pd.nxt_org = P;
+        if (useIS) { att = att_in * Kd; bsdf_pdf = cos_out / kPIf; }
+        else       { att = att_in * Kd * (2.0f * cos_out); bsdf_pdf = 1.0f / (2.0f * kPIf); }
+    } else if (bsdf == PT_BSDF_METALLIC) {
+        const float z1 = rnd(s);
+        const float z2 = rnd(s);
+        const f3 mn = sample_ggx(z1, z2, 0.2f, N);
+        const f3 R = reflect(dir, mn);
+        pd.nxt_dir = R;
+        pd.nxt_org = P + R * 1e-4f;
+        const f3 eta = mk(1.45f, 0.7f, 1.55f), kk = mk(3.0f, 2.2f, 3.5f);
+        const float cosTheta = fmaxf(dot(mn, -dir), 0.0f);
+        att = att_in * (fresnel_conductor(cosTheta, eta, kk) * Kd);
+    } else if (bsdf == PT_BSDF_REFRACTION) {
+        const f3 inc = normalize(dir);
+        const float cos_theta = dot(normalize(-dir), N0);
+        const float F = fr_dielectric(cos_theta, 1.0f, mp->ior);
+        if (rnd(s) < F) {
+            pd.nxt_dir = reflect(inc, N0);
+        } else {
+            f3 rd;
+            pd.nxt_dir = refract_dir(rd, inc, N0, mp->ior) ? rd : reflect(inc, N0);
+        }
+        pd.nxt_org = P + pd.nxt_dir * 1e-3f;
+        att = att_in * Kd;
+    }
+    const float z1 = rnd(s);
+    const float z2 = rnd(s);
+    pseed = s;
+    prev_pdf = 0.0f;
+    bool want_shadow = false;
+    if (useDL && bsdf == PT_BSDF_DIFFUSE) {
+        const float target = z1 * area_total;
+        uint32_t k = 0;
+        while (k + 1u < sc.n_lights && !(target < sc.lights[5u * k + 1u].w)) k++;
+        const float4 l0 = sc.lights[5u * k], l1 = sc.lights[5u * k + 1u], l2 = sc.lights[5u * k + 2u], l3 = sc.lights[5u * k + 3u], l4 = sc.lights[5u * k + 4u];
+        const float lo = k ? sc.lights[5u * (k - 1u) + 1u].w : 0.0f;
+        const float u = fminf(fmaxf((target - lo) / l0.w, 0.0f), 0.99999994f);
+        const float su = sqrtf(u);
+        const f3 light_pos = mk(l0.x, l0.y, l0.z) + mk(l1.x, l1.y, l1.z) * (su * (1.0f - z2)) + mk(l2.x, l2.y, l2.z) * (su * z2);
+        const f3 Lv = light_pos - P;
+        const float dist2 = dot(Lv, Lv);
+        Ldist = sqrtf(dist2);
+        L = Lv / Ldist;
+        const float nDl = dot(N, L);
+        const float LnDl = fabsf(dot(mk(l3.x, l3.y, l3.z), L));
+        prev_pdf = bsdf_pdf;
+        want_shadow = nDl > 0.0f && LnDl > 0.0f;
+        const float p_l = dist2 / (area_total * LnDl);
+        const float p_b = useIS ? nDl / kPIf : 1.0f / (2.0f * kPIf);
+        const float w = (p_l * p_l) / (p_l * p_l + p_b * p_b);
+        const float geom = nDl * LnDl * area_total / (kPIf * dist2);
+        if (want_shadow) pd.radiance = att_in * Kd * mk(l4.x, l4.y, l4.z) * (geom * w);      // counted only if the shadow ray finds nothing
+    }
+    return want_shadow;
+}
+
 }  // namespace ptd

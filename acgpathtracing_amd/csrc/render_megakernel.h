@@ -13,7 +13,7 @@ constexpr uint32_t kMaxTimedWaves = 16384;   // stats variants stamp start / que
 // scene tried so far): the five-waves-per-SIMD kernel when five workgroups' lane stacks fit a CU's LDS (trees up to ~28
 // levels), else the four-wave sign-rotated one.  fp32 nodes otherwise, with triangle rounds at 8 lanes above kLargeSceneTris.
 constexpr int kVariantSync = 0, kVariantF32 = 1, kVariantF32Stats = 2, kVariantF32Large = 3, kVariantFastMath = 4;
-constexpr int kVariantF16 = 5, kVariantF16Stats = 6, kVariantF16W5 = 7;
+constexpr int kVariantF16 = 5, kVariantF16Stats = 6, kVariantF16W5 = 7, kVariantLights = 8;
 constexpr int kDefaultVariant = kVariantF16W5;
 constexpr uint32_t kLargeSceneTris = 100000;
 constexpr float kHalfAreaLimit = 1.05f;

@@ -208,19 +208,19 @@ __device__ __forceinline__ void write_frame_sum(const RenderArgs& A, uint32_t pi
     A.frame_sums[(size_t)pix * A.n_frames + f] = make_float4(sum.x, sum.y, sum.z, 0.0f);
 }
 
-// Two / four consecutive 16-byte loads served by the L2 (sc1: agent scope), not by whatever an earlier use of the addresses
-// left in this CU's L1, all in flight together and waited for inside the same asm block (the compiler never sees a
+// Two / four consecutive 16-byte loads served by the L2 (sc0: past this CU's L1, whatever an earlier use of the addresses
+// left there; the partial sums were written by this very CU, so the L2 of its XCD holds them and nothing has to leave it), all in flight together and waited for inside the same asm block (the compiler never sees a
 // register whose load has not landed).
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void load2_coherent(const float4* p, v4f_t& a, v4f_t& b)
 {
-    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+    asm volatile("global_load_dwordx4 %0, %2, off sc0\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc0\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(a), "=&v"(b) : "v"(p) : "memory");
 }
 __device__ __forceinline__ void load4_coherent(const float4* p, v4f_t& a, v4f_t& b, v4f_t& c, v4f_t& d)
 {
-    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
-                 "global_load_dwordx4 %2, %4, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc1\n\ts_waitcnt vmcnt(0)"
+    asm volatile("global_load_dwordx4 %0, %4, off sc0\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc0\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32 sc0\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc0\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p) : "memory");
 }
 
@@ -245,7 +245,7 @@ __device__ __forceinline__ void finish_runs(const RenderArgs& A, const LanePixel
     }
     if (vote(folder) == 0ull) return;
     // the partial sums were stored by lanes of this wave through this CU's L1: wait for the stores, then read them back
-    // past the L1 (agent-scope loads), whatever lines an earlier use of the slot left there
+    // past the L1 (sc0 loads), whatever lines an earlier use of the slot left there
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0) only
     if (folder) {
@@ -474,7 +474,7 @@ __device__ __forceinline__ void setup_ray(const f3& ro, const f3& rd, const QGri
 // INNER: 0 = stack entirely in LDS, nested branches; 1 = stack top cached in a register (the LDS read of
 // a pop is consumed one push/pop later, off the critical path) and child selection by selects; 2, 3 = the same with
 // that many node visits per trip through the loop control.
-template <int SHADE_K, int LEAF_K, int NODE_FMT, int THREADS, int MINW, bool STATS, int DIAG = 0, int INNER = 0, int LEAVES = 1>
+template <int SHADE_K, int LEAF_K, int NODE_FMT, int THREADS, int MINW, bool STATS, int DIAG = 0, int INNER = 0, int LEAVES = 1, bool LIGHTS = false>
 __global__ void __launch_bounds__(THREADS, MINW)
 k_render_pw(const RenderArgsBox B)
 {
@@ -523,6 +523,7 @@ k_render_pw(const RenderArgsBox B)
     int node = kSentinel, sp = 0, tos = kSentinel;
     uint32_t cur_base = 0, cur_list = 0;              // NODE_FMT 3: innermost group of pending children
     bool shadow_ray = false, shadow_hit = false;
+    float prev_pdf = 0.0f;                            // LIGHTS (light mode 1) only: pdf of the last sampled direction where a light sample was taken
     bool fin_pending = false;                         // ran out of samples inside the camera cull: its run is finished at the next round's start
     // held while the shadow ray is in flight
     Pending pd; pd.nxt_org = mk(0.0f); pd.nxt_dir = mk(0.0f, 0.0f, 1.0f); pd.radiance = mk(0.0f); pd.weight = 0.0f; pd.done = true;
@@ -536,14 +537,16 @@ k_render_pw(const RenderArgsBox B)
         f3 emission = mk(0.0f);
         if (lp.alive && node == kSentinel) {
             if (shadow_ray) {                                         // shadow ray back (:1015-1024)
-                if (!shadow_hit) pd.radiance += mk(late().light.emission) * pd.weight;
+                if (LIGHTS) { if (shadow_hit) pd.radiance = mk(0.0f); }                // the light sample parked there counts only unoccluded
+                else if (!shadow_hit) pd.radiance += mk(late().light.emission) * pd.weight;
                 shadow_ray = false;
                 segment_done = true;
             } else {                                                  // radiance ray back
                 bool want_shadow = false;
                 f3 P, L; float Ldist;
                 if (best_slot >= 0) {
-                    want_shadow = shade_hit<DIAG == 3>(sc, late, ro, rd, best_t, best_slot, depth, pseed, att, emission, pd, P, L, Ldist);
+                    if (LIGHTS) want_shadow = shade_hit_lights(sc, late, ro, rd, best_t, best_slot, depth, pseed, att, prev_pdf, pd, P, L, Ldist);
+                    else want_shadow = shade_hit<DIAG == 3>(sc, late, ro, rd, best_t, best_slot, depth, pseed, att, emission, pd, P, L, Ldist);
                 } else {                                              // __miss__ms :833-847
                     pd.radiance = mk(0.0f); pd.weight = 0.0f; pd.done = true;
                 }
@@ -562,8 +565,10 @@ k_render_pw(const RenderArgsBox B)
         n_shadow += (unsigned long long)popc(vote(started_shadow));
         bool end = false, finished = false;
         if (segment_done) {                                           // raygen :761-778
-            lp.result += pd.radiance * att;
-            const float p = dot(att, mk(0.30f, 0.59f, 0.11f));
+            if (LIGHTS) lp.result += pd.radiance;                     // light mode 1: already times the throughput
+            else lp.result += pd.radiance * att;
+            float p = dot(att, mk(0.30f, 0.59f, 0.11f));
+            if (LIGHTS) p = fminf(p, 1.0f);                           // the 2 cos weight can lift the throughput above 1; a survival probability is <= 1
             const bool rr = rnd(pseed) > p;
             end = pd.done || rr || (uint32_t)depth >= A.maxDepth;
             if (!end) {
@@ -614,6 +619,7 @@ k_render_pw(const RenderArgsBox B)
                 att = mk(1.0f);
                 pseed = lp.seed;
                 depth = 0;
+                prev_pdf = 0.0f;
                 lp.new_path = false;
                 start_radiance = true;
             }
@@ -1262,6 +1268,7 @@ static const VariantDesc kVariants[] = {
     {k_render_pw<44, 16, 8, 256, 4, false, 0, 3, 2>, 256, 8, "pw K44 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes, w4, three visits and two triangle tests per loop trip"},
     {k_render_pw<44, 16, 8, 256, 4, true, 0, 3, 2>, 256, 8, "pw K44 L16 fp16 sign-rotated nodes + scheduler stats"},
     {k_render_pw<44, 16, 7, 256, 5, false, 0, 3, 2>, 256, 7, "pw K44 L16 fp16 nodes (32 B), v_fma_mix planes with per-axis min / max, FIVE waves per SIMD (96 registers), three visits and two triangle tests per loop trip"},
+    {k_render_pw<44, 16, 8, 256, 4, false, 0, 3, 2, true>, 256, 8, "LIGHTS scene-driven area lights + MIS (light mode 1, opt-in: not the reference's estimator), fp16 sign-rotated nodes w4"},
 #ifdef ACGPT_EXPERIMENTS
     {k_render_pw<40, 8, 0, 256, 4, false, 0, 1>, 256, 0, "pw K40 L8 fp32 w4, register stack top"},
     {k_render_pw<48, 8, 0, 256, 4, false>, 256, 0, "pw K48 L8 fp32 w4, LDS-only stack"},

@@ -181,6 +181,15 @@ int pt_set_partition(pt_ctx* ctx, int rank, int world);
  * a float4 DEVICE array and writes uchar4 into frameBuffer (device or mapped host).          */
 int pt_resolve_framebuffer(pt_ctx* ctx, const float* accumulation_rgba, uint8_t* framebuffer_rgba, size_t n_pixels);
 
+/* Light mode (strictly opt-in, the default 0 is the reference bit for bit).
+ *   0  the reference's estimator: the rectangle of params->areaLight (hard-coded at PathTracerMain.cpp:154-158), light
+ *      samples and BSDF-sampled light hits both counted (pathTracerPrograms.cu:992-1026), the emitter quirks of a8/a9;
+ *   1  the area light is the scene's own emissive triangles (materials with Ke != 0; params->areaLight is ignored), light
+ *      sampling by area, combined with BSDF sampling by the power heuristic; a seen light contributes Ke, uniform
+ *      hemisphere sampling carries its 2 cos weight: direct lighting on / off and importance sampling on / off converge to
+ *      the same image.  Same random draws per segment as mode 0.  One kernel variant serves it (pt_variant_name "LIGHTS").  */
+int pt_set_light_mode(pt_ctx* ctx, int mode);
+
 /* Sample chunks (1, 2, 4, 8, 16, 32; 0 = automatic, the default: 8 runs per pixel, 16 when this rank
  * holds fewer than 2^20 pixels, 32 below 2^19, reduced until every run keeps at least 4 samples).  With c > 1 a pixel's samplesPerPixel samples are cut into
  * c consecutive runs, each owned by its own lane with the PRNG skipped ahead to where the run
@@ -197,7 +206,8 @@ int pt_set_sample_chunks(pt_ctx* ctx, int chunks);
  * with deferred shading, see csrc/render_megakernel.hip.  Every variant produces the same image bits.   */
 int pt_set_tuning(pt_ctx* ctx, int blocks_per_cu, int variant);
 /* Human-readable description of a kernel variant, NULL past the last one.  Names starting with "DIAG"
- * are timing experiments (some deliberately compute different bits) and are never selected by default. */
+ * are timing experiments (some deliberately compute different bits) and are never selected by default; "FAST-MATH" and
+ * "LIGHTS" (the kernel of pt_set_light_mode(1)) are opt-in and compute other bits than the reference's estimator. */
 const char* pt_variant_name(int variant);
 
 /* Stream the launches are enqueued on (a hipStream_t, e.g. torch's current

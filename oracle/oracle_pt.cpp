@@ -273,12 +273,18 @@ static inline bool tri_test(const f3& o, const f3& d, const f3& v0, const f3& e1
 struct Tri { f3 v0, e1, e2; };
 struct BNode { float lo[3], hi[3]; uint32_t left, right, first, count; };  /* count>0: leaf */
 
+/* One emissive triangle of the scene (light mode 1, see closesthit_scene_lights): geometry, unit normal, emission, and
+ * the running sum of the areas up to and including this one (the selection CDF). */
+struct LightTri { f3 v0, e1, e2, n, Ke; float area, cdf; };
+
 struct Scene {
     std::vector<Tri> tris;
     std::vector<uint32_t> mat_ids;
     std::vector<pt_material> mats;
     std::vector<BNode> nodes;
     std::vector<uint32_t> order;   /* leaf triangle order */
+    std::vector<LightTri> lights;  /* emissive triangles in triangle order */
+    int light_mode;                /* 0 = the reference's estimator (hard-coded rectangle, double counting); 1 = scene lights + MIS */
 };
 
 static void tri_bounds(const Tri& t, float lo[3], float hi[3])
@@ -531,6 +537,143 @@ static inline void closesthit(const Scene& sc, const pt_params& params, int use_
     }
 }
 
+/* ---------------------------------------------------------- light mode 1 (NOT the reference) ----
+ * SURVEY.md section 8 f4, opt-in: the area light is what the OBJ says is emissive (every triangle whose material has
+ * Ke != 0) instead of the rectangle hard-coded at PathTracerMain.cpp:154-158, and the estimator is a consistent one:
+ *   - next-event estimation samples a point on the emissive triangles uniformly by area (z1 picks the triangle through
+ *     the area CDF and, rescaled, is the first barycentric variate; z2 the second) — the same two draws the reference
+ *     makes at :985-986, so the random streams stay aligned with mode 0;
+ *   - a BSDF-sampled ray that hits an emitter and the light sample are combined with the power heuristic (Veach) instead
+ *     of being added twice (:992-1000 + :1003-1026);
+ *   - a directly seen emitter contributes Ke (mode 0: Ke + Ke * Kd), an emitter reached by a bounce
+ *     throughput * Ke (mode 0: throughput * Kd_emitter * Ke);
+ *   - uniform hemisphere sampling carries its 2 cos(theta) weight (mode 0 omits it), so importance sampling
+ *     on / off and direct lighting on / off all converge to the same image;
+ *   - conductor and dielectric keep the reference's directions and throughput; they take no light sample (their
+ *     emitter hits count in full).
+ * `contrib` is everything this segment adds to the pixel, already multiplied by the path throughput. */
+static inline float light_pdf_area_to_solid(float dist2, float cos_l, float area_total) { return dist2 / (area_total * cos_l); }
+
+static inline void closesthit_scene_lights(const Scene& sc, const pt_params& params, int use_bvh,
+                                           const f3& ray_org, const f3& ray_dir, float t_hit, uint32_t prim_idx,
+                                           PRD& prd, float& prev_pdf, f3& contrib, Counters& cnt)
+{
+    const pt_material& rt = sc.mats[sc.mat_ids[prim_idx]];
+    const Tri& tri = sc.tris[prim_idx];
+    const bool useDirectLighting = params.useDirectLighting != 0 && !sc.lights.empty();
+    const bool useImportanceSampling = params.useImportanceSampling != 0;
+    const int bsdfType = rt.bsdfType;
+    const f3 N_0 = normalize(cross(tri.e1, tri.e2));
+    const f3 N = faceforward(N_0, -ray_dir, N_0);
+    const f3 P = ray_org + t_hit * ray_dir;
+    const f3 Kd = mk(rt.diffuse), Ke = mk(rt.emission);
+    const float area_total = sc.lights.empty() ? 0.0f : sc.lights.back().cdf;
+    contrib = mk(0.0f);
+    prd.emissionColor = mk(0.0f);
+    prd.radiance = mk(0.0f);
+
+    uint32_t seed = prd.randomSeed;
+    if (length(Ke) > 0.0f) {
+        /* an emitter ends the path (as :992-1000); seen directly it counts in full, reached by a sampled bounce that also
+         * took a light sample it gets the BSDF strategy's share */
+        float w = 1.0f;
+        if (prd.depth > 0 && prev_pdf > 0.0f) {
+            const float cos_l = fabsf(dot(N_0, ray_dir));
+            const float p_l = light_pdf_area_to_solid(t_hit * t_hit, cos_l, area_total);
+            w = cos_l > 0.0f ? (prev_pdf * prev_pdf) / (prev_pdf * prev_pdf + p_l * p_l) : 1.0f;
+        }
+        contrib = prd.attenuation * Ke * w;
+        /* the reference's draws of this segment, so that the stream position does not depend on what was hit */
+        if (bsdfType == PT_BSDF_REFRACTION) (void)rnd(seed); else { (void)rnd(seed); (void)rnd(seed); }
+        (void)rnd(seed); (void)rnd(seed);
+        prd.randomSeed = seed;
+        prd.done = 1;
+        return;
+    }
+    prd.done = 0;
+    const f3 att_in = prd.attenuation;
+    float bsdf_pdf = 0.0f;                 /* solid-angle pdf of the sampled continuation; 0 = no light sample taken here */
+    switch (bsdfType) {
+    case PT_BSDF_DIFFUSE: {
+        const float z1 = rnd(seed);
+        const float z2 = rnd(seed);
+        OrthonormalBasis onb(N);
+        f3 w_in;
+        if (useImportanceSampling) cosine_sample_hemisphere(z1, z2, w_in);
+        else                       uniform_sample_hemisphere(z1, z2, w_in);
+        const float cos_out = w_in.z;
+        onb.inverse_transform(w_in);
+        prd.direction = w_in;
+        prd.origin = P;
+        if (useImportanceSampling) { prd.attenuation = att_in * Kd; bsdf_pdf = cos_out / kPIf; }
+        else                       { prd.attenuation = att_in * Kd * (2.0f * cos_out); bsdf_pdf = 1.0f / (2.0f * kPIf); }
+        break;
+    }
+    case PT_BSDF_METALLIC: {
+        const float z1 = rnd(seed);
+        const float z2 = rnd(seed);
+        f3 microfacetNormal = sampleGGX(z1, z2, 0.2f, N);
+        f3 R = reflect(ray_dir, microfacetNormal);
+        prd.direction = R;
+        prd.origin = P + R * 1e-4f;
+        f3 eta = mk((float)1.45, (float)0.7, (float)1.55);
+        f3 k = mk((float)3.0, (float)2.2, (float)3.5);
+        float cosTheta = fmaxf(dot(microfacetNormal, -ray_dir), 0.0f);
+        prd.attenuation = att_in * (fresnelSchlickConductor(cosTheta, eta, k) * Kd);
+        break;
+    }
+    case PT_BSDF_REFRACTION: {
+        f3 incidentRayDir = normalize(ray_dir);
+        float cos_theta = dot(normalize(-ray_dir), N_0);
+        float F = FrDielectric(cos_theta, 1.0f, rt.ior);
+        if (rnd(seed) < F) {
+            prd.direction = reflect(incidentRayDir, N_0);
+        } else {
+            f3 refractedDir;
+            bool didRefract = refract(refractedDir, incidentRayDir, N_0, rt.ior);
+            prd.direction = didRefract ? refractedDir : reflect(incidentRayDir, N_0);
+        }
+        prd.origin = P + prd.direction * 1e-3f;
+        prd.attenuation = att_in * Kd;
+        break;
+    }
+    default: break;
+    }
+    const float z1 = rnd(seed);
+    const float z2 = rnd(seed);
+    prd.randomSeed = seed;
+    prev_pdf = 0.0f;
+    if (useDirectLighting && bsdfType == PT_BSDF_DIFFUSE) {
+        /* pick the triangle whose CDF interval holds z1 * A, reuse the position inside the interval as first variate */
+        const float target = z1 * area_total;
+        size_t k = 0;
+        while (k + 1 < sc.lights.size() && !(target < sc.lights[k].cdf)) k++;
+        const LightTri& lt = sc.lights[k];
+        const float lo = k ? sc.lights[k - 1].cdf : 0.0f;
+        const float u = fminf(fmaxf((target - lo) / lt.area, 0.0f), 0.99999994f);
+        const float su = sqrtf(u);
+        const f3 light_pos = lt.v0 + lt.e1 * (su * (1.0f - z2)) + lt.e2 * (su * z2);
+        const f3 Lv = light_pos - P;
+        const float dist2 = dot(Lv, Lv);
+        const float Ldist = sqrtf(dist2);
+        const f3 L = Lv / Ldist;
+        const float nDl = dot(N, L);
+        const float LnDl = fabsf(dot(lt.n, L));
+        prev_pdf = bsdf_pdf;               /* this vertex takes a light sample: a later emitter hit is MIS-weighted */
+        if (nDl > 0.0f && LnDl > 0.0f) {
+            cnt.shadow_rays++;
+            const bool occluded = use_bvh ? any_bvh(sc, P, L, 0.01f, Ldist - 0.01f) : any_brute(sc, P, L, 0.01f, Ldist - 0.01f);
+            if (!occluded) {
+                const float p_l = light_pdf_area_to_solid(dist2, LnDl, area_total);
+                const float p_b = useImportanceSampling ? nDl / kPIf : 1.0f / (2.0f * kPIf);
+                const float w = (p_l * p_l) / (p_l * p_l + p_b * p_b);
+                const float geom = nDl * LnDl * area_total / (kPIf * dist2);      /* (Kd / pi) cos / p_area-as-solid-angle, Kd below */
+                contrib = att_in * Kd * lt.Ke * (geom * w);
+            }
+        }
+    }
+}
+
 /* __raygen__rg, pathTracerPrograms.cu:707-816, for launch index (x, y) */
 static void raygen_pixel(const Scene& sc, const pt_params& params, int use_bvh, int chunks, uint32_t x, uint32_t y,
                          float* accumulation, uint8_t* framebuffer, Counters& cnt)
@@ -561,13 +704,18 @@ static void raygen_pixel(const Scene& sc, const pt_params& params, int use_bvh, 
         prd.attenuation = mk(1.f);
         prd.randomSeed = seed;
         prd.depth = 0;
+        float prev_pdf = 0.0f;             /* light mode 1 only */
         cnt.paths++;
         for (;;) {
             Hit hit;
             cnt.radiance_rays++;
             if (use_bvh) closest_bvh(sc, ray_origin, ray_direction, 0.01f, 1e16f, hit);
             else         closest_brute(sc, ray_origin, ray_direction, 0.01f, 1e16f, hit);
-            if (hit.prim != 0xFFFFFFFFu) {
+            if (hit.prim != 0xFFFFFFFFu && sc.light_mode == 1) {
+                f3 contrib;
+                closesthit_scene_lights(sc, params, use_bvh, ray_origin, ray_direction, hit.t, hit.prim, prd, prev_pdf, contrib, cnt);
+                result += contrib;         /* already carries the throughput; prd.emissionColor / radiance are zero */
+            } else if (hit.prim != 0xFFFFFFFFu) {
                 closesthit(sc, params, use_bvh, ray_origin, ray_direction, hit.t, hit.prim, prd, cnt);
             } else {                                   /* __miss__ms :833-847, background 0 (PathTracerMain.cpp:568) */
                 prd.radiance = mk(0.0f);
@@ -576,7 +724,8 @@ static void raygen_pixel(const Scene& sc, const pt_params& params, int use_bvh, 
             }
             result += prd.emissionColor;               /* :760-761 */
             result += prd.radiance * prd.attenuation;
-            const float p = dot(prd.attenuation, mk(0.30f, 0.59f, 0.11f));
+            float p = dot(prd.attenuation, mk(0.30f, 0.59f, 0.11f));
+            if (sc.light_mode == 1) p = fminf(p, 1.0f);   /* mode 1: the 2 cos weight can lift the throughput above 1; a survival probability is <= 1 */
             bool russianRoulette = rnd(prd.randomSeed) > p;
             const bool done = prd.done || russianRoulette || (unsigned)prd.depth >= maxDepth;
             if (done) break;
@@ -752,9 +901,25 @@ ORC_API void* orc_scene_create(const float* verts_xyzw, size_t n_verts, const ui
     }
     if (mat_ids) sc->mat_ids.assign(mat_ids, mat_ids + n_tris);
     if (mats) sc->mats.assign(mats, mats + n_mats);
+    sc->light_mode = 0;
+    if (mat_ids && mats) {
+        float run = 0.0f;
+        for (size_t i = 0; i < n_tris; i++) {
+            const f3 Ke = mk(mats[mat_ids[i]].emission);
+            if (!(length(Ke) > 0.0f)) continue;
+            const f3 c = cross(sc->tris[i].e1, sc->tris[i].e2);
+            const float area = 0.5f * length(c);
+            if (!(area > 0.0f)) continue;
+            LightTri lt; lt.v0 = sc->tris[i].v0; lt.e1 = sc->tris[i].e1; lt.e2 = sc->tris[i].e2; lt.n = normalize(c); lt.Ke = Ke; lt.area = area;
+            run += area; lt.cdf = run;
+            sc->lights.push_back(lt);
+        }
+    }
     build_bvh(*sc);
     return sc;
 }
+/* 0: the reference's estimator; 1: scene lights + MIS (closesthit_scene_lights).  Returns the number of light triangles. */
+ORC_API int orc_scene_set_light_mode(void* s, int mode) { Scene* sc = (Scene*)s; sc->light_mode = mode == 1 ? 1 : 0; return (int)sc->lights.size(); }
 ORC_API void orc_scene_destroy(void* s) { delete (Scene*)s; }
 
 ORC_API void orc_trace_closest(void* s, const float* rays, size_t n, int use_bvh, float* t_out, uint32_t* prim_out)

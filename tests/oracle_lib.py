@@ -45,6 +45,7 @@ class Oracle(MathMixin):
         L.orc_trace_any.argtypes = [vp, vp, sz, C.c_int, vp]; L.orc_trace_any.restype = None
         L.orc_render.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]; L.orc_render.restype = C.c_double
         L.orc_render_window.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]; L.orc_render_window.restype = C.c_double
+        L.orc_scene_set_light_mode.argtypes = [vp, C.c_int]; L.orc_scene_set_light_mode.restype = C.c_int
         L.orc_uses_hw_fma.argtypes = []; L.orc_uses_hw_fma.restype = C.c_int
 
     # -- small functions -------------------------------------------------------------
@@ -106,6 +107,10 @@ class OracleScene:
                                           C.addressof(mats) if len(mats) else None, len(mats))
         if not self.h:
             raise ValueError("oracle: invalid scene (index out of range)")
+
+    def set_light_mode(self, mode):
+        """0: the reference's estimator; 1: scene lights + MIS.  Returns the number of emissive triangles."""
+        return int(self.orc.lib.orc_scene_set_light_mode(self.h, int(mode)))
 
     def close(self):
         if self.h:

@@ -260,7 +260,7 @@ def test_every_kernel_variant_gives_the_same_bits(full):
             name = L.pt_variant_name(v)
             if name is None:
                 break
-            if name.startswith(b"DIAG") or name.startswith(b"FAST-MATH") or L.pt_set_tuning(state.context, 0, v) != 0:
+            if name.startswith(b"DIAG") or name.startswith(b"FAST-MATH") or name.startswith(b"LIGHTS") or L.pt_set_tuning(state.context, 0, v) != 0:
                 continue
             acc, fb, st = _gpu_render(state, p)
             tried += 1
@@ -571,6 +571,49 @@ def test_headline_config3_windows(gpu_state_factory, oracle):
     w = {k: HEADLINE_WINDOWS[k] for k in ("glass sphere", "metal mesh", "light edge")}
     w = {k: (x, y, 32, 32) for k, (x, y, _, _) in w.items()}
     _headline_check(gpu_state_factory, oracle, SCENE_FULL, 16, 8, w, "config 3")
+
+
+def test_light_mode_scene_lights_and_mis(full, diffuse):
+    """SURVEY.md section 8 f4, opt-in: pt_set_light_mode(1) takes the area light from the scene's emissive triangles and
+    combines light and BSDF sampling by the power heuristic.  (a) GPU against the oracle's twin of the same estimator, every
+    toggle combination, both scenes; (b) what the mode is for: direct lighting on / off and importance sampling on / off
+    converge to the same image, which the reference's estimator (mode 0) does not; (c) mode 0 is untouched."""
+    L = _native.hip()
+    for name, (state, obj, sc) in (("diffuse", diffuse), ("glass + metal", full)):
+        p0 = make_params(96, 72, 8, 8, True, True)
+        before, _, _ = _gpu_render(state, p0)                      # mode 0
+        n_lights = sc.set_light_mode(1)
+        assert n_lights == 2                                       # the ceiling quad of the OBJ
+        try:
+            assert L.pt_set_light_mode(state.context, 1) == 0
+            for dl, isamp in ((True, True), (False, True), (True, False), (False, False)):
+                p = make_params(96, 72, 8, 8, dl, isamp)
+                acc, _, st = _gpu_render(state, p)
+                assert b"LIGHTS" in L.pt_variant_name(int(st[0].variant))
+                ref, _, ref_st, _ = sc.render(copy_params(p), use_bvh=True)
+                mse = image_mse(acc, ref)
+                same = float(np.all(acc.view(np.uint32) == ref.view(np.uint32), axis=-1).mean())
+                print("light mode 1, %s, DL %d IS %d: MSE %.3e, %.1f%% pixels bit-identical" % (name, dl, isamp, mse, 100 * same))
+                assert np.isfinite(acc).all() and mse < MSE_TOL and same > 0.60
+                assert abs(int(st[0].radiance_rays) - ref_st["radiance_rays"]) <= 2e-3 * ref_st["radiance_rays"]
+                assert abs(int(st[0].shadow_rays) - ref_st["shadow_rays"]) <= 2e-3 * max(1, ref_st["shadow_rays"])
+            if name == "diffuse":                                  # (b) 48 x 36 pixels x 1024 spp: image means
+                means = {}
+                for mode in (1, 0):
+                    assert L.pt_set_light_mode(state.context, mode) == 0
+                    for dl, isamp in ((True, True), (False, True), (True, False)):
+                        acc, _, _ = _gpu_render(state, make_params(48, 36, 256, 12, dl, isamp), frames=4)
+                        means[(mode, dl, isamp)] = float(acc[..., :3].mean())
+                print("image means:", {k: round(v, 4) for k, v in means.items()})
+                m1 = [means[(1, True, True)], means[(1, False, True)], means[(1, True, False)]]
+                assert max(m1) / min(m1) < 1.03, "mode 1: the toggles must agree within noise"
+                assert means[(0, True, True)] / means[(0, False, True)] > 1.2, "mode 0 counts the light twice with direct lighting on"
+            assert L.pt_set_light_mode(state.context, 2) != 0
+        finally:
+            assert L.pt_set_light_mode(state.context, 0) == 0
+            sc.set_light_mode(0)
+        after, _, _ = _gpu_render(state, p0)                       # (c)
+        assert np.array_equal(before.view(np.uint32), after.view(np.uint32))
 
 
 def test_full_size_properties(diffuse):

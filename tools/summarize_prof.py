@@ -13,6 +13,10 @@ def main():
     d = sys.argv[1]
     kern = sys.argv[2] if len(sys.argv) > 2 else "k_render"
     out = {"dir": os.path.basename(d.rstrip("/")), "kernel_filter": kern}
+    if len(sys.argv) > 3:
+        out["command"] = sys.argv[3]
+    if len(sys.argv) > 4:
+        out["steps_per_kernel_launch"] = int(sys.argv[4])
     st = os.path.join(d, "trace", "trace_kernel_stats.csv")
     if os.path.exists(st):
         for r in csv.DictReader(open(st)):
