@@ -46,7 +46,7 @@ struct pt_ctx {
     int rank = 0, world = 1;
     int chunks = 0;                           // sample chunks per pixel: 0 = automatic, else 1/2/4/8/16
     float4* d_frame_sums = nullptr; size_t frame_sums_bytes = 0;   // [pixel][sub-frame] of a frame batch
-    float4* d_wave_scratch = nullptr; size_t wave_scratch_bytes = 0;   // fold slots of every wave of the grid
+    float* d_wave_scratch = nullptr; size_t wave_scratch_bytes = 0;    // fold slots of every wave of the grid
     size_t scratch_limit = (size_t)1 << 30;                          // a frame batch is cut into launches whose frame sums fit
     pt_stats stats;
     uint64_t scene_serial = 0;
@@ -476,7 +476,7 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
     if (grid < 1) grid = 1;
 
     if (a.chunk_shift) {   // fold slots for every wave of the grid
-        const size_t need = (size_t)grid * wpb * ((size_t)ptd::kRenderFoldSlots << a.chunk_shift) * sizeof(float4);
+        const size_t need = (size_t)grid * wpb * ((size_t)ptd::kRenderFoldSlots << a.chunk_shift) * 3 * sizeof(float);
         if (need > c->wave_scratch_bytes) {
             CK(c, hipStreamSynchronize(c->stream));
             if (c->d_wave_scratch) { (void)hipFree(c->d_wave_scratch); c->d_wave_scratch = nullptr; c->wave_scratch_bytes = 0; }

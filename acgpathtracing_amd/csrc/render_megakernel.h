@@ -49,7 +49,7 @@ struct RenderArgs {
     uint32_t  lcg_mul[32];     // seed of chunk k = lcg_mul[k] * seed0 + lcg_add[k]  (2 * k * chunk_spp LCG steps)
     uint32_t  lcg_add[32];
     float4*   frame_sums;      // [pixel][n_frames] sums of the sub-frames of a batch (n_frames > 1): k_finalize blends them in order
-    float4*   wave_scratch;    // [wave of the grid][kFoldSlots << chunk_shift] partial sums of runs whose group is still open (chunk_shift > 0)
+    float*    wave_scratch;    // [wave of the grid][kFoldSlots << chunk_shift][3] partial sums of runs whose group is still open (chunk_shift > 0)
     uint32_t  grant;           // minimum work items taken per queue atomic (1 = exactly what is needed)
     uint32_t  strip_cols;      // tile-strip columns of StaticWorkDistribution for (width, world)
     FastDiv   div_cols, div_world;

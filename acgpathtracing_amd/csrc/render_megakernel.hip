@@ -211,23 +211,23 @@ __device__ __forceinline__ void write_frame_sum(const RenderArgs& A, uint32_t pi
 // Two / four consecutive 16-byte loads served by the L2 (sc0: past this CU's L1, whatever an earlier use of the addresses
 // left there; the partial sums were written by this very CU, so the L2 of its XCD holds them and nothing has to leave it), all in flight together and waited for inside the same asm block (the compiler never sees a
 // register whose load has not landed).
-typedef float v4f_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void load2_coherent(const float4* p, v4f_t& a, v4f_t& b)
+typedef float v3f_t __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void load2_coherent(const float* p, v3f_t& a, v3f_t& b)
 {
-    asm volatile("global_load_dwordx4 %0, %2, off sc0\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc0\n\ts_waitcnt vmcnt(0)"
+    asm volatile("global_load_dwordx3 %0, %2, off sc0\n\tglobal_load_dwordx3 %1, %2, off offset:12 sc0\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(a), "=&v"(b) : "v"(p) : "memory");
 }
-__device__ __forceinline__ void load4_coherent(const float4* p, v4f_t& a, v4f_t& b, v4f_t& c, v4f_t& d)
+__device__ __forceinline__ void load4_coherent(const float* p, v3f_t& a, v3f_t& b, v3f_t& c, v3f_t& d)
 {
-    asm volatile("global_load_dwordx4 %0, %4, off sc0\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc0\n\t"
-                 "global_load_dwordx4 %2, %4, off offset:32 sc0\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc0\n\ts_waitcnt vmcnt(0)"
+    asm volatile("global_load_dwordx3 %0, %4, off sc0\n\tglobal_load_dwordx3 %1, %4, off offset:12 sc0\n\t"
+                 "global_load_dwordx3 %2, %4, off offset:24 sc0\n\tglobal_load_dwordx3 %3, %4, off offset:36 sc0\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p) : "memory");
 }
 
 // Lanes with `finished` set have completed their run of samples.  One run per pixel: write.  Several: park the partial
 // sum in the group's fold slot, bump the slot's ticket, and the lane that completes the group adds the runs in order.
-// scratch: this wave's kFoldSlots << chunk_shift float4.
-__device__ __forceinline__ void finish_runs(const RenderArgs& A, const LanePixel& lp, bool finished, const WaveBook& book, float4* __restrict__ scratch)
+// scratch: this wave's (kFoldSlots << chunk_shift) partial sums, three floats each.
+__device__ __forceinline__ void finish_runs(const RenderArgs& A, const LanePixel& lp, bool finished, const WaveBook& book, float* __restrict__ scratch)
 {
     if (vote(finished) == 0ull) return;
     const uint32_t cs = A.chunk_shift, runs = 1u << cs;
@@ -237,10 +237,11 @@ __device__ __forceinline__ void finish_runs(const RenderArgs& A, const LanePixel
         return;
     }
     const uint32_t slot = lp.tag >> 16;
-    float4* group = scratch + ((size_t)slot << cs);
+    float* group = scratch + 3u * ((size_t)slot << cs);
     bool folder = false;
     if (finished) {
-        group[sub & (runs - 1u)] = make_float4(lp.result.x, lp.result.y, lp.result.z, 0.0f);
+        float* mine = group + 3u * (sub & (runs - 1u));
+        mine[0] = lp.result.x; mine[1] = lp.result.y; mine[2] = lp.result.z;
         folder = book.bump(slot) == runs - 1u;                       // LDS: lanes of one group that finish together get distinct counts
     }
     if (vote(folder) == 0ull) return;
@@ -252,14 +253,14 @@ __device__ __forceinline__ void finish_runs(const RenderArgs& A, const LanePixel
         // the loads of four runs in flight at once (one latency per four runs, not one per run)
         f3 sum = mk(0.0f);
         if (runs == 2u) {
-            v4f_t p0, p1;
+            v3f_t p0, p1;
             load2_coherent(group, p0, p1);
             sum = mk(p0.x, p0.y, p0.z);
             sum += mk(p1.x, p1.y, p1.z);
         } else {
             for (uint32_t k0 = 0; k0 < runs; k0 += 4u) {
-                v4f_t p0, p1, p2, p3;
-                load4_coherent(group + k0, p0, p1, p2, p3);
+                v3f_t p0, p1, p2, p3;
+                load4_coherent(group + 3u * k0, p0, p1, p2, p3);
                 if (k0 == 0u) sum = mk(p0.x, p0.y, p0.z); else sum += mk(p0.x, p0.y, p0.z);      // the chain starts at run 0, not at zero
                 sum += mk(p1.x, p1.y, p1.z);
                 sum += mk(p2.x, p2.y, p2.z);
@@ -344,7 +345,7 @@ k_render(const RenderArgsBox B)
 
     QueueState q; q.shard = xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.grant_g0 = 0; q.grp_pxy = 0xFFFFFFFFu; q.grp_seed = 0; q.grp_slot = kNoSlot;
     unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0;
-    float4* const scratch = A.wave_scratch + (size_t)(blockIdx.x * (kRenderThreads / 64) + wave) * ((size_t)kFoldSlots << A.chunk_shift);
+    float* const scratch = A.wave_scratch + 3u * (size_t)(blockIdx.x * (kRenderThreads / 64) + wave) * ((size_t)kFoldSlots << A.chunk_shift);
 
     LanePixel lp; lp.alive = false; lp.new_path = false; lp.pxy = lp.seed = lp.samples_left = lp.tag = 0; lp.result = mk(0.0f);
     uint32_t pseed = 0;
@@ -503,7 +504,7 @@ k_render_pw(const RenderArgsBox B)
     const int root = sc.n_tris ? 0 : kSentinel;
 
     QueueState q; q.shard = xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.grant_g0 = 0; q.grp_pxy = 0xFFFFFFFFu; q.grp_seed = 0; q.grp_slot = kNoSlot;
-    float4* const scratch = A.wave_scratch + (size_t)(blockIdx.x * (THREADS / 64) + wave) * ((size_t)kFoldSlots << A.chunk_shift);
+    float* const scratch = A.wave_scratch + 3u * (size_t)(blockIdx.x * (THREADS / 64) + wave) * ((size_t)kFoldSlots << A.chunk_shift);
     unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0;
     unsigned long long n_steps = 0, n_lane_steps = 0, n_rounds = 0, n_lane_rounds = 0;
     // STATS only: 100 MHz stamps of this wave's start, of the moment it found the queue empty, and of its end

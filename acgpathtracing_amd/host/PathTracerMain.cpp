@@ -158,7 +158,7 @@ int main(int argc, char** argv)
     std::string objfilepath, out = "frame.png", keys;
     int32_t width = 512, height = 512, frames = 8, dump_every = 0;
     bool zero_copy = false;
-    int orbit_dx = 0, orbit_dy = 0, zoom_steps = 0, sample_chunks = 0, build_mode = 1, fuse = 1;
+    int orbit_dx = 0, orbit_dy = 0, zoom_steps = 0, sample_chunks = 0, build_mode = 1, fuse = 1, light_mode = 0;
     PathTracerState state;
     state.params.useDirectLighting = false;
     state.params.useImportanceSampling = false;
@@ -184,6 +184,7 @@ int main(int argc, char** argv)
         else if (a == "--sample-chunks") sample_chunks = atoi(next());
         else if (a == "--build-mode") build_mode = atoi(next());
         else if (a == "--fuse-frames") fuse = std::min(64, std::max(1, atoi(next())));
+        else if (a == "--light-mode") light_mode = atoi(next());      // 0 = the reference's hard-coded rectangle (:154-158), 1 = the OBJ's emissive triangles + MIS
         else { std::cerr << "unknown option " << a << std::endl; return 2; }
     }
     if (objfilepath.empty()) { std::cerr << "usage: acgpt_main --obj scene.obj [options]" << std::endl; return 2; }
@@ -217,6 +218,7 @@ int main(int argc, char** argv)
         createDeviceContext(state);
         PT_CHECK(state.context, pt_set_build_mode(state.context, build_mode));
         PT_CHECK(state.context, pt_set_sample_chunks(state.context, sample_chunks));
+        PT_CHECK(state.context, pt_set_light_mode(state.context, light_mode));
         buildTheAccelarationStructure(state, obj);
         std::cout << "Acceleration Structure Built" << std::endl;
         initializeTheLaunch(state);

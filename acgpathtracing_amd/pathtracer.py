@@ -328,6 +328,13 @@ def LaunchCurrentFrame(output_buffer, state, sub_frames=1):
     _check(state.context, rc, "LaunchCurrentFrame")
 
 
+def setLightMode(state, mode):
+    """0: the reference's estimator (hard-coded rectangle, PathTracerMain.cpp:154-158; the default).  1: the scene's own
+    emissive triangles as the area light, light and BSDF sampling combined by the power heuristic (opt-in)."""
+    _check(state.context, _native.hip().pt_set_light_mode(state.context, int(mode)), "pt_set_light_mode")
+    state.refreshAccumulationBuffer = True
+
+
 def getStats(state):
     s = Stats()
     _check(state.context, _native.hip().pt_get_stats(state.context, C.byref(s)), "pt_get_stats")
