@@ -197,6 +197,9 @@ def roofline_block(a, info, world, fuse, kernel_ms, rays_per_launch, steps_per_l
                     "hbm_GBps": (traffic / (summ["kernel_stats"]["avg_ms"] * 1e-3) / 1e9) if traffic and summ.get("kernel_stats") else None}
     r = {"kernel": variant_name, "kernel_ms_avg": k_avg_ms, "scene_bytes": scene_bytes, "scene_resident_in": resident,
          "traffic": traffic, "measured": measured,
+         "traffic_note": ("bytes between L2 and the fabric per kernel launch (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section); "
+                          + ("reads that the 256 MB Infinity Cache serves are included: an upper bound on HBM traffic" if resident == "Infinity Cache"
+                             else "HBM traffic")),
          "hbm_model": {"algorithmic_bytes_per_ray": b_ray, "algorithmic_bytes_per_launch": algo_bytes, "GBps": model_gbs,
                        "note": "SURVEY.md 8d byte model; for a cache-resident scene these bytes are served by L1/L2/Infinity Cache, so this is not an HBM fraction"},
          "valu_model": {"algorithmic_flops_per_ray": f_ray, "TFLOPs": valu_tf, "frac_of_fp32_vector_peak": valu_tf / FP32_PEAK_TFLOPS}}
