@@ -47,6 +47,7 @@ struct pt_ctx {
     int chunks = 0;                           // sample chunks per pixel: 0 = automatic, else 1/2/4/8/16
     float4* d_frame_sums = nullptr; size_t frame_sums_bytes = 0;   // [pixel][sub-frame] of a frame batch
     float* d_wave_scratch = nullptr; size_t wave_scratch_bytes = 0;    // fold slots of every wave of the grid
+    uint32_t* d_stack_ovf = nullptr; size_t stack_ovf_bytes = 0;       // stack entries beyond a kernel's LDS cap
     size_t scratch_limit = (size_t)1 << 30;                          // a frame batch is cut into launches whose frame sums fit
     pt_stats stats;
     uint64_t scene_serial = 0;
@@ -119,6 +120,7 @@ PT_API void pt_destroy(pt_ctx* c)
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_frame_sums) (void)hipFree(c->d_frame_sums);
     if (c->d_wave_scratch) (void)hipFree(c->d_wave_scratch);
+    if (c->d_stack_ovf) (void)hipFree(c->d_stack_ovf);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -132,7 +134,7 @@ static int pick_variant(const pt_ctx* c)
     if (!half_ok) return large ? ptd::kVariantF32Large : ptd::kVariantF32;
     int w5_blocks = 0;      // do five workgroups of the five-wave kernel fit a CU with this tree's stack depth?
     if (ptd::render_occupancy(ptd::kVariantF16W5, c->stack_entries, c->bvh.n_nodes, &w5_blocks) == hipSuccess && w5_blocks >= 5) return ptd::kVariantF16W5;
-    return ptd::kVariantF16;
+    return ptd::kVariantF16W5Deep;      // deep tree: 28 stack entries per lane in LDS, the rest in global memory (1 % ahead of four waves on 1.31 M triangles)
 }
 
 // dwords per lane: one push per internal node on a root-to-leaf path at most (two-child tree), or one
@@ -484,6 +486,19 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
             c->wave_scratch_bytes = need;
         }
         a.wave_scratch = c->d_wave_scratch;
+    }
+    {   // kernels whose LDS stack is capped keep deeper entries here
+        const uint32_t cap = (uint32_t)ptd::render_variant_stack_cap(variant);
+        if (cap > 0u && c->stack_entries > cap) {
+            const size_t need = (size_t)grid * wpb * 64u * (c->stack_entries - cap) * sizeof(uint32_t);
+            if (need > c->stack_ovf_bytes) {
+                CK(c, hipStreamSynchronize(c->stream));
+                if (c->d_stack_ovf) { (void)hipFree(c->d_stack_ovf); c->d_stack_ovf = nullptr; c->stack_ovf_bytes = 0; }
+                CK(c, hipMalloc((void**)&c->d_stack_ovf, need));
+                c->stack_ovf_bytes = need;
+            }
+            a.stack_overflow = c->d_stack_ovf;
+        }
     }
     CK(c, hipMemsetAsync(c->d_queue, 0, 8 * sizeof(uint32_t), c->stream));
     CK(c, hipMemsetAsync(c->d_counters, 0, (8 + 3 * (size_t)ptd::kMaxTimedWaves + 2056) * sizeof(unsigned long long), c->stream));

@@ -10,10 +10,10 @@ constexpr uint32_t kRenderFoldSlots = 128;  // fold slots per wave (render_megak
 constexpr uint32_t kMaxTimedWaves = 16384;   // stats variants stamp start / queue-empty / end per wave behind the 8 counters
 // Variant indices of the product library (render_megakernel.hip kVariants).  pt_set_scene picks one per scene unless
 // pt_set_tuning named one.  fp16 nodes when the fp16 planes cost less than kHalfAreaLimit in summed child-box area (every
-// scene tried so far): the five-waves-per-SIMD kernel when five workgroups' lane stacks fit a CU's LDS (trees up to ~28
-// levels), else the four-wave sign-rotated one.  fp32 nodes otherwise, with triangle rounds at 8 lanes above kLargeSceneTris.
+// scene tried so far): the five-waves-per-SIMD kernel; when five workgroups' lane stacks do not fit a CU's LDS (trees deeper
+// than ~28 levels) the same kernel with the stack's tail in global memory.  fp32 nodes otherwise, with triangle rounds at 8 lanes above kLargeSceneTris.
 constexpr int kVariantSync = 0, kVariantF32 = 1, kVariantF32Stats = 2, kVariantF32Large = 3, kVariantFastMath = 4;
-constexpr int kVariantF16 = 5, kVariantF16Stats = 6, kVariantF16W5 = 7, kVariantLights = 8;
+constexpr int kVariantF16 = 5, kVariantF16Stats = 6, kVariantF16W5 = 7, kVariantLights = 8, kVariantF16W5Deep = 9;
 constexpr int kDefaultVariant = kVariantF16W5;
 constexpr uint32_t kLargeSceneTris = 100000;
 constexpr float kHalfAreaLimit = 1.05f;
@@ -35,6 +35,7 @@ struct RenderArgs {
     uint32_t* queue_heads;     // 8 counters, zeroed before the launch
     unsigned long long* counters;   // [8 + 3 * kMaxTimedWaves] radiance rays, shadow rays, paths, pixels, traversal wave-steps, lane-steps, shade rounds, shade lanes
     uint32_t  stack_entries;
+    uint32_t* stack_overflow;  // kernels with a capped LDS stack: [wave of the grid][stack_entries - cap][64] deeper entries
     uint32_t  n_lds_nodes;     // nodes staged into LDS (NODE_FMT 2), else 0
     // sample chunks: a pixel's spp samples may be split into 2^chunk_shift consecutive runs, each run
     // owned by its own lane (shortens the per-pixel serial chain when a GPU has few pixels).
@@ -59,6 +60,7 @@ struct RenderArgs {
 int render_variant_count();
 const char* render_variant_name(int variant);
 int render_variant_threads(int variant);
+int render_variant_stack_cap(int variant);      // 0 = the whole stack in LDS
 int render_variant_node_format(int variant);   // 0 fp32 two-child, 7 fp16 two-child; experiments: 1/2/4 16-bit grid, 3 four-wide 8-bit
 hipError_t render_occupancy(int variant, uint32_t stack_entries, uint32_t n_nodes, int* blocks_per_cu);
 hipError_t launch_render(int variant, const RenderArgs& args, uint32_t grid_blocks, hipStream_t stream);

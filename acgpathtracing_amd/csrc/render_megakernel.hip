@@ -475,28 +475,34 @@ __device__ __forceinline__ void setup_ray(const f3& ro, const f3& rd, const QGri
 // INNER: 0 = stack entirely in LDS, nested branches; 1 = stack top cached in a register (the LDS read of
 // a pop is consumed one push/pop later, off the critical path) and child selection by selects; 2, 3 = the same with
 // that many node visits per trip through the loop control.
-template <int SHADE_K, int LEAF_K, int NODE_FMT, int THREADS, int MINW, bool STATS, int DIAG = 0, int INNER = 0, int LEAVES = 1, bool LIGHTS = false>
+template <int SHADE_K, int LEAF_K, int NODE_FMT, int THREADS, int MINW, bool STATS, int DIAG = 0, int INNER = 0, int LEAVES = 1, bool LIGHTS = false, int STACK_CAP = 0>
 __global__ void __launch_bounds__(THREADS, MINW)
 k_render_pw(const RenderArgsBox B)
 {
     const RenderArgs& A = B.a[0];                     // what the BVH loop, the queue and the wave set-up use: read once
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
+    // STACK_CAP > 0: only the first STACK_CAP entries of a lane's stack live in LDS (so that a deep tree does not cost a
+    // resident workgroup); the few rays that ever hold more pending nodes keep the rest in global memory (A.stack_overflow)
+    const uint32_t lds_entries = (STACK_CAP > 0 && A.stack_entries > (uint32_t)STACK_CAP) ? (uint32_t)STACK_CAP : A.stack_entries;
     LaneStack st;
-    st.base = lds_dyn + wave * (A.stack_entries * 64u) + lane;
+    st.base = lds_dyn + wave * (lds_entries * 64u) + lane;
+    uint32_t* const ovf = STACK_CAP > 0 ? A.stack_overflow + (size_t)(blockIdx.x * (THREADS / 64) + wave) * 64u * (A.stack_entries - lds_entries) + lane : nullptr;
+    const auto push = [&](int at, int v) { if (STACK_CAP == 0 || at < (int)lds_entries) st.push(at, v); else ovf[(at - (int)lds_entries) * 64] = (uint32_t)v; };
+    const auto pop = [&](int at) -> int { if (STACK_CAP == 0 || at < (int)lds_entries) return st.pop(at); return (int)ovf[(at - (int)lds_entries) * 64]; };
     LaneStack2 st2;                                   // NODE_FMT 3: the same LDS region as stack_entries / 2 groups
-    st2.base = (uint2*)(lds_dyn + wave * (A.stack_entries * 64u)) + lane;
+    st2.base = (uint2*)(lds_dyn + wave * (lds_entries * 64u)) + lane;
     DeviceScene sc = A.scene;
     if (NODE_FMT == 3) sc.tris = (const TriRecord*)A.scene.wrecs;      // triangles live in the record array
-    const uint2* lds_nodes = (const uint2*)(lds_dyn + (THREADS / 64) * (A.stack_entries * 64u));
+    const uint2* lds_nodes = (const uint2*)(lds_dyn + (THREADS / 64) * (lds_entries * 64u));
     if (NODE_FMT == 2) {
-        uint4* dst = (uint4*)(lds_dyn + (THREADS / 64) * (A.stack_entries * 64u));
+        uint4* dst = (uint4*)(lds_dyn + (THREADS / 64) * (lds_entries * 64u));
         const uint4* src = (const uint4*)sc.qnodes;
         for (uint32_t i = threadIdx.x; i < A.n_lds_nodes * 2u; i += THREADS) dst[i] = src[i];
         __syncthreads();
     }
     // LCG skip-ahead table behind the stacks (and behind the LDS-staged nodes of NODE_FMT 2)
-    uint32_t* const lcg_skip = lds_dyn + (THREADS / 64) * (A.stack_entries * 64u) + (NODE_FMT == 2 ? A.n_lds_nodes * 8u : 0u);
+    uint32_t* const lcg_skip = lds_dyn + (THREADS / 64) * (lds_entries * 64u) + (NODE_FMT == 2 ? A.n_lds_nodes * 8u : 0u);
     if (threadIdx.x < 32u) { lcg_skip[2u * threadIdx.x] = A.lcg_mul[threadIdx.x]; lcg_skip[2u * threadIdx.x + 1u] = A.lcg_add[threadIdx.x]; }
     const WaveBook book = wave_book(lcg_skip + 64u + wave * kBookDwords, lane);
     __syncthreads();
@@ -832,7 +838,7 @@ k_render_pw(const RenderArgsBox B)
                 if (INNER == 0) {
                     if (h0 && h1) {
                         const bool first0 = n0 <= n1;
-                        st.push(sp, first0 ? c1 : c0);
+                        push(sp, first0 ? c1 : c0);
                         sp++;
                         node = first0 ? c0 : c1;
                     } else if (h0) {
@@ -840,20 +846,20 @@ k_render_pw(const RenderArgsBox B)
                     } else if (h1) {
                         node = c1;
                     } else {
-                        if (sp == 0) node = kSentinel; else { sp--; node = st.pop(sp); }
+                        if (sp == 0) node = kSentinel; else { sp--; node = pop(sp); }
                     }
                 } else {
                     // elements e_1..e_sp, e_sp in `tos`, e_k (k < sp) in LDS slot k
                     const bool first0 = n0 <= n1;
                     const int near_c = (h0 && (first0 || !h1)) ? c0 : c1;
                     const int far_c = first0 ? c1 : c0;
-                    if (h0 && h1) { st.push(sp, tos); tos = far_c; sp++; }
+                    if (h0 && h1) { push(sp, tos); tos = far_c; sp++; }
                     if (h0 || h1) {
                         node = near_c;
                     } else {
                         node = sp ? tos : kSentinel;
                         sp = sp ? sp - 1 : 0;
-                        tos = st.pop(sp);
+                        tos = pop(sp);
                     }
                 }
             }
@@ -875,11 +881,11 @@ k_render_pw(const RenderArgsBox B)
                         else if (t < best_t || (t == best_t && prim < best_prim)) { best_t = t; best_slot = slot; best_prim = prim; }
                     }
                     if (INNER == 0) {
-                        if (stop || sp == 0) node = kSentinel; else { sp--; node = st.pop(sp); }
+                        if (stop || sp == 0) node = kSentinel; else { sp--; node = pop(sp); }
                     } else {
                         node = (stop || sp == 0) ? kSentinel : tos;
                         sp = sp ? sp - 1 : 0;
-                        tos = st.pop(sp);
+                        tos = pop(sp);
                     }
                 }
             }
@@ -1254,7 +1260,7 @@ hipError_t trace_stream_occupancy(int fmt, uint32_t stack_entries, int* blocks_p
 // ---- host-side launchers ------------------------------------------------------------------
 typedef void (*RenderKernel)(const RenderArgsBox);
 
-struct VariantDesc { RenderKernel k; int threads; int node_fmt; const char* name; };
+struct VariantDesc { RenderKernel k; int threads; int node_fmt; const char* name; int stack_cap = 0; };
 
 // Render kernel variants.  0: segment-synchronous (fp32 nodes).  Others: persistent traversal
 // <SHADE_K, LEAF_K, NODE_FMT, THREADS, MINW, STATS, DIAG, INNER, LEAVES>.  The product library carries the variants a user
@@ -1270,6 +1276,7 @@ static const VariantDesc kVariants[] = {
     {k_render_pw<44, 16, 8, 256, 4, true, 0, 3, 2>, 256, 8, "pw K44 L16 fp16 sign-rotated nodes + scheduler stats"},
     {k_render_pw<44, 16, 7, 256, 5, false, 0, 3, 2>, 256, 7, "pw K44 L16 fp16 nodes (32 B), v_fma_mix planes with per-axis min / max, FIVE waves per SIMD (96 registers), three visits and two triangle tests per loop trip"},
     {k_render_pw<44, 16, 8, 256, 4, false, 0, 3, 2, true>, 256, 8, "LIGHTS scene-driven area lights + MIS (light mode 1, opt-in: not the reference's estimator), fp16 sign-rotated nodes w4"},
+    {k_render_pw<44, 16, 7, 256, 5, false, 0, 3, 2, false, 28>, 256, 7, "pw K44 L16 fp16 nodes, five waves per SIMD for deep trees: 28 stack entries per lane in LDS, deeper ones in global memory", 28},
 #ifdef ACGPT_EXPERIMENTS
     {k_render_pw<40, 8, 0, 256, 4, false, 0, 1>, 256, 0, "pw K40 L8 fp32 w4, register stack top"},
     {k_render_pw<48, 8, 0, 256, 4, false>, 256, 0, "pw K48 L8 fp32 w4, LDS-only stack"},
@@ -1326,9 +1333,11 @@ int render_variant_count() { return (int)(sizeof(kVariants) / sizeof(kVariants[0
 const char* render_variant_name(int v) { return (v >= 0 && v < render_variant_count()) ? kVariants[v].name : "?"; }
 int render_variant_node_format(int v) { return (v >= 0 && v < render_variant_count()) ? kVariants[v].node_fmt : -1; }
 int render_variant_threads(int v) { return (v >= 0 && v < render_variant_count()) ? kVariants[v].threads : 0; }
+int render_variant_stack_cap(int v) { return (v >= 0 && v < render_variant_count()) ? kVariants[v].stack_cap : 0; }
 
 static size_t variant_lds(const VariantDesc& d, uint32_t stack_entries, uint32_t n_nodes)
 {
+    if (d.stack_cap > 0 && stack_entries > (uint32_t)d.stack_cap) stack_entries = (uint32_t)d.stack_cap;
     size_t lds = (size_t)(d.threads / 64) * (stack_entries * 256u + kBookDwords * 4u) + 256u;      // lane stacks, fold bookkeeping, LCG skip-ahead table
     if (d.node_fmt == 2) lds += (size_t)n_nodes * sizeof(QNode);
     return lds;
