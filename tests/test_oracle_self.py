@@ -80,3 +80,22 @@ def test_partition_sums_to_whole(scene):
             total += part; rays += s["radiance_rays"]
         assert np.array_equal(total.view(np.uint32), whole.view(np.uint32))
         assert rays == st["radiance_rays"]
+
+
+def test_light_mode_1_is_a_consistent_estimator(oracle):
+    """The oracle's twin of pt_set_light_mode(1) (scene lights + MIS): direct lighting on / off and
+    importance sampling on / off must converge to the same image — which the reference's estimator (mode 0: light counted
+    twice, no 2 cos weight) does not — and the random streams stay aligned with mode 0 (same number of radiance rays)."""
+    obj = pt.TinyObjWrapper(pt.SCENES + "/cornell_box_diffuse.obj")
+    sc = oracle.scene(obj.getVerticesFloat(), obj.getIndexBuffer(), obj.getMaterialIndices(), obj.getMaterials())
+    means, rays = {}, {}
+    for mode in (0, 1):
+        assert sc.set_light_mode(mode) == 2                      # the ceiling quad
+        for dl, isamp in ((True, True), (False, True), (True, False)):
+            acc, _, st, _ = sc.render(make_params(32, 32, 192, 10, dl, isamp), use_bvh=True)
+            means[(mode, dl, isamp)] = float(acc[..., :3].mean()); rays[(mode, dl, isamp)] = st["radiance_rays"]
+    m1 = [means[(1, True, True)], means[(1, False, True)], means[(1, True, False)]]
+    assert max(m1) / min(m1) < 1.05, m1
+    assert means[(0, True, True)] / means[(0, False, True)] > 1.2
+    sc.set_light_mode(0)
+    sc.close()
