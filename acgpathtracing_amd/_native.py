@@ -65,7 +65,7 @@ assert C.sizeof(AreaLight) == 60
 # every symbol include/acgpt.h declares
 ABI_SYMBOLS = [
     "pt_create", "pt_destroy", "pt_last_error", "pt_set_scene", "pt_set_build_mode", "pt_scene_handle", "pt_get_bvh_info",
-    "pt_launch", "pt_launch_frames", "pt_resolve_framebuffer", "pt_set_partition", "pt_set_sample_chunks", "pt_set_light_mode", "pt_set_tuning", "pt_variant_name", "pt_set_stream", "pt_get_stats",
+    "pt_launch", "pt_launch_frames", "pt_resolve_framebuffer", "pt_set_partition", "pt_set_sample_chunks", "pt_set_light_mode", "pt_set_scratch_limit", "pt_set_tuning", "pt_variant_name", "pt_set_stream", "pt_get_stats",
     "pt_trace_closest", "pt_trace_any", "pt_bench_traversal", "pt_selftest", "pt_debug_wave_times", "pt_debug_queue_progress", "pt_read_morton",
     "pt_device_malloc", "pt_device_free", "pt_device_memset", "pt_copy_to_host", "pt_copy_to_device",
     "pt_host_malloc_mapped", "pt_host_free_mapped", "pt_abi_version",
@@ -112,6 +112,7 @@ def hip():
     L.pt_set_partition.argtypes = [vp, C.c_int, C.c_int]; L.pt_set_partition.restype = C.c_int
     L.pt_set_sample_chunks.argtypes = [vp, C.c_int]; L.pt_set_sample_chunks.restype = C.c_int
     L.pt_set_light_mode.argtypes = [vp, C.c_int]; L.pt_set_light_mode.restype = C.c_int
+    L.pt_set_scratch_limit.argtypes = [vp, C.c_size_t]; L.pt_set_scratch_limit.restype = C.c_int
     L.pt_set_tuning.argtypes = [vp, C.c_int, C.c_int]; L.pt_set_tuning.restype = C.c_int
     L.pt_variant_name.argtypes = [C.c_int]; L.pt_variant_name.restype = C.c_char_p
     L.pt_set_stream.argtypes = [vp, vp]; L.pt_set_stream.restype = C.c_int

@@ -170,6 +170,11 @@ int pt_launch(pt_ctx* ctx, const pt_params* params);
  * the ramp-up and drain of n_frames - 1 launches.  n_frames in [1, 64].              */
 int pt_launch_frames(pt_ctx* ctx, const pt_params* params, uint32_t n_frames);
 
+/* Upper bound on the per-launch scratch of a frame batch (one float4 per pixel and sub-frame, held until the batch is
+ * blended into the accumulation buffer): pt_launch_frames runs a batch whose sums would not fit as several kernel
+ * launches — same bits.  Default 1 GiB (32 sub-frames at 1920x1080); at least 1 MiB.                                   */
+int pt_set_scratch_limit(pt_ctx* ctx, size_t bytes);
+
 /* Multi-GPU pixel partition: this context renders only the pixels that
  * sutil/WorkDistribution.h:50-81 assigns to `rank` of `world` (interleaved 8x4
  * tiles, rotated per strip row); other pixels of the buffers are left

@@ -242,6 +242,15 @@ def test_frame_batches_equal_separate_launches(full, chunks):
             q = copy_params(p); q.currentFrameIdx = f
             ref, _, _, _ = sc.render(q, accumulation=ref, use_bvh=True)
         assert image_mse(want_acc, ref) < MSE_TOL
+        # a batch whose frame sums exceed the scratch limit runs as several kernel launches: same bits, summed counters
+        assert L.pt_set_scratch_limit(state.context, 1 << 20) == 0            # 1 MiB = 4 sub-frames of 160 x 96 float4
+        try:
+            acc, fb, st = _gpu_render(state, p, frames=8, fuse=8)
+            assert np.array_equal(acc.view(np.uint32), want_acc.view(np.uint32)) and np.array_equal(fb, want_fb)
+            assert len(st) == 1 and int(st[0].paths) == 160 * 96 * 8 * 8 and int(st[0].radiance_rays + st[0].shadow_rays) == rays1
+        finally:
+            assert L.pt_set_scratch_limit(state.context, 1 << 30) == 0
+        assert L.pt_set_scratch_limit(state.context, 1000) != 0
         assert L.pt_launch_frames(state.context, C.byref(state.params), 0) != 0 and L.pt_launch_frames(state.context, C.byref(state.params), 65) != 0
     finally:
         assert L.pt_set_sample_chunks(state.context, 1) == 0
