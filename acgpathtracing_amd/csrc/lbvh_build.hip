@@ -371,10 +371,16 @@ __device__ __forceinline__ float merged_area(const float4& al, const float4& ah,
     return dx * dy + dy * dz + dz * dx;
 }
 
-__global__ void k_ploc_nn(const Cluster* __restrict__ c, uint32_t m, uint32_t* __restrict__ nn)
+// The round loop runs on the device's own counters: PlocState holds the current cluster count and the next free node number,
+// every kernel of a round reads them, the last one advances them.  The host enqueues rounds in batches and looks at the
+// count once per batch, instead of synchronising (and copying four words back) after every round.
+struct PlocState { uint32_t m, next_top, kept, made, rounds, pad0, pad1, pad2; };
+
+__global__ void k_ploc_nn(const Cluster* __restrict__ c, const PlocState* __restrict__ st, uint32_t* __restrict__ nn)
 {
+    const uint32_t m = st->m;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
+    if (i >= m || m < 2u) return;
     const float4 l = c[i].lo, h = c[i].hi;
     const uint32_t a = i > (uint32_t)kPlocRadius ? i - kPlocRadius : 0u;
     const uint32_t b = min(m, i + kPlocRadius + 1u);
@@ -388,23 +394,49 @@ __global__ void k_ploc_nn(const Cluster* __restrict__ c, uint32_t m, uint32_t* _
 }
 
 // keep[i] = 1 if position i survives (unmerged, or the lower partner of a merge); made[i] = 1 if a node is created at i
-__global__ void k_ploc_flags(const uint32_t* __restrict__ nn, uint32_t m, uint32_t* __restrict__ keep, uint32_t* __restrict__ made)
+__global__ void k_ploc_flags(const uint32_t* __restrict__ nn, const PlocState* __restrict__ st, uint32_t* __restrict__ keep, uint32_t* __restrict__ made)
 {
+    const uint32_t m = st->m;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
+    if (i >= m || m < 2u) return;
     const uint32_t j = nn[i];
     const bool mutual = (j != i) && (nn[j] == i);
     keep[i] = (!mutual || i < j) ? 1u : 0u;
     made[i] = (mutual && i < j) ? 1u : 0u;
 }
 
-__global__ void k_ploc_merge(const Cluster* __restrict__ cin, const uint32_t* __restrict__ nn, uint32_t m,
-                             const uint32_t* __restrict__ keep_pos, const uint32_t* __restrict__ made_pos,
-                             uint32_t next_node_top /* highest free node number */, Cluster* __restrict__ cout,
-                             BvhNode* __restrict__ nodes, QNode* __restrict__ qnodes, const uint32_t* __restrict__ scene_bounds)
+// exclusive scans of keep[] and made[] over the current clusters, in place, one workgroup; totals into the state
+__global__ void __launch_bounds__(1024) k_ploc_scan(uint32_t* __restrict__ keep, uint32_t* __restrict__ made, PlocState* __restrict__ st)
 {
+    __shared__ uint32_t pk[1024], pm[1024];
+    const uint32_t count = st->m;
+    if (count < 2u) return;
+    const uint32_t per = (count + 1023u) / 1024u;
+    const uint32_t b = threadIdx.x * per, e = min(count, b + per);
+    uint32_t sk = 0, sm = 0;
+    for (uint32_t i = b; i < e; i++) { sk += keep[i]; sm += made[i]; }
+    pk[threadIdx.x] = sk; pm[threadIdx.x] = sm;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        const uint32_t vk = threadIdx.x >= off ? pk[threadIdx.x - off] : 0u, vm = threadIdx.x >= off ? pm[threadIdx.x - off] : 0u;
+        __syncthreads();
+        pk[threadIdx.x] += vk; pm[threadIdx.x] += vm;
+        __syncthreads();
+    }
+    uint32_t rk = pk[threadIdx.x] - sk, rm = pm[threadIdx.x] - sm;
+    for (uint32_t i = b; i < e; i++) { const uint32_t vk = keep[i], vm = made[i]; keep[i] = rk; made[i] = rm; rk += vk; rm += vm; }
+    if (threadIdx.x == 1023u) { st->kept = pk[1023]; st->made = pm[1023]; }
+}
+
+__global__ void k_ploc_merge(const Cluster* __restrict__ cin, const uint32_t* __restrict__ nn, const PlocState* __restrict__ st,
+                             const uint32_t* __restrict__ keep_pos, const uint32_t* __restrict__ made_pos,
+                             Cluster* __restrict__ cout, BvhNode* __restrict__ nodes, QNode* __restrict__ qnodes, const uint32_t* __restrict__ scene_bounds)
+{
+    const uint32_t m = st->m;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < 2u) { if (i == 0u) cout[0] = cin[0]; return; }     // finished: the host's blind ping-pong still finds the root cluster
     if (i >= m) return;
+    const uint32_t next_node_top = st->next_top;                  // highest free node number
     const uint32_t j = nn[i];
     const bool mutual = (j != i) && (nn[j] == i);
     if (mutual && i > j) return;                   // absorbed by its partner
@@ -426,6 +458,15 @@ __global__ void k_ploc_merge(const Cluster* __restrict__ cin, const uint32_t* __
         me = u;
     }
     cout[keep_pos[i]] = me;
+}
+
+// after the merge of a round: the survivors are the new sequence
+__global__ void k_ploc_advance(PlocState* __restrict__ st)
+{
+    if (st->m < 2u) return;
+    st->next_top -= st->made;
+    st->m = st->kept;
+    st->rounds += 1u;
 }
 
 
@@ -606,31 +647,30 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
         HIPCK(sc.alloc(&d_keep, ((size_t)n + 1) * 4));
         HIPCK(sc.alloc(&d_made, ((size_t)n + 1) * 4));
         k_ploc_init<<<blocks, 256, 0, stream>>>(d_vals[cur], n, d_tlo, d_thi, d_c[0]);
-        uint32_t m = n, next_top = n - 2;      // node numbers n-2 ... 0, root last = 0
+        PlocState* d_st;
+        HIPCK(sc.alloc(&d_st, sizeof(PlocState)));
+        PlocState h_st = {n, n - 2u, 0u, 0u, 0u, 0u, 0u, 0u};      // node numbers n-2 ... 0, root last = 0
+        HIPCK(hipMemcpyAsync(d_st, &h_st, sizeof(h_st), hipMemcpyHostToDevice, stream));
         int pc = 0;
-        uint32_t iters = 0;
-        while (m > 1) {
-            const uint32_t mb = (m + 255) / 256;
-            k_ploc_nn<<<mb, 256, 0, stream>>>(d_c[pc], m, d_nn);
-            k_ploc_flags<<<mb, 256, 0, stream>>>(d_nn, m, d_keep, d_made);
-            uint32_t last[2];
-            HIPCK(hipMemcpyAsync(&last[0], d_keep + (m - 1), 4, hipMemcpyDeviceToHost, stream));
-            HIPCK(hipMemcpyAsync(&last[1], d_made + (m - 1), 4, hipMemcpyDeviceToHost, stream));
-            k_scan<<<1, 1024, 0, stream>>>(d_keep, m);
-            k_scan<<<1, 1024, 0, stream>>>(d_made, m);
-            uint32_t tail[2];
-            HIPCK(hipMemcpyAsync(&tail[0], d_keep + (m - 1), 4, hipMemcpyDeviceToHost, stream));
-            HIPCK(hipMemcpyAsync(&tail[1], d_made + (m - 1), 4, hipMemcpyDeviceToHost, stream));
-            k_ploc_merge<<<mb, 256, 0, stream>>>(d_c[pc], d_nn, m, d_keep, d_made, next_top, d_c[pc ^ 1], out.nodes, out.qnodes, d_bounds);
+        uint32_t m_ub = n;              // what the host knows the cluster count does not exceed: sizes the grids
+        const int kBatch = 8;           // rounds enqueued between two looks at the device's count
+        for (int guard = 0; m_ub > 1u; guard++) {
+            if (guard > 4096) { err = "PLOC made no progress"; return false; }
+            const uint32_t mb = (m_ub + 255) / 256;
+            for (int r = 0; r < kBatch; r++) {
+                k_ploc_nn<<<mb, 256, 0, stream>>>(d_c[pc], d_st, d_nn);
+                k_ploc_flags<<<mb, 256, 0, stream>>>(d_nn, d_st, d_keep, d_made);
+                k_ploc_scan<<<1, 1024, 0, stream>>>(d_keep, d_made, d_st);
+                k_ploc_merge<<<mb, 256, 0, stream>>>(d_c[pc], d_nn, d_st, d_keep, d_made, d_c[pc ^ 1], out.nodes, out.qnodes, d_bounds);
+                k_ploc_advance<<<1, 1, 0, stream>>>(d_st);
+                pc ^= 1;
+            }
+            HIPCK(hipMemcpyAsync(&h_st, d_st, sizeof(h_st), hipMemcpyDeviceToHost, stream));
             HIPCK(hipStreamSynchronize(stream));
-            const uint32_t kept = tail[0] + last[0], merged = tail[1] + last[1];
-            if (merged == 0 || kept >= m) { err = "PLOC made no progress"; return false; }
-            next_top -= merged;
-            m = kept;
-            pc ^= 1;
-            iters++;
+            if (h_st.m >= m_ub && h_st.m > 1u) { err = "PLOC made no progress"; return false; }
+            m_ub = h_st.m;
         }
-        out.build_iterations = iters;
+        out.build_iterations = h_st.rounds;
         // the last cluster carries the root's height
         HIPCK(hipMemcpyAsync(d_nhi, &d_c[pc][0].hi, 16, hipMemcpyDeviceToDevice, stream));
     } else if (n > 1) {
