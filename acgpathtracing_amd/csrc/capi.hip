@@ -423,9 +423,13 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
     }
     // items per queue atomic.  A grant is decoded once, by up to 64 lanes side by side (one (pixel, step) group each), so it holds
     // at most 64 groups; within that, larger grants mean fewer atomics and decodes (64 -> 256 items at 8 runs: -1.3 % at full
-    // size, -3.6 % when a rank holds 1/8 of the tiles, profiles/r02_sweep_grant.txt)
-    static const uint32_t grant_by_shift[6] = {32u, 64u, 128u, 256u, 256u, 256u};
-    a.grant = grant_by_shift[a.chunk_shift];
+    // size, -3.6 % when a rank holds 1/8 of the tiles, profiles/r02_sweep_grant.txt).  A scene that does not fit one XCD's 4 MB
+    // of L2 wants the opposite: a wave's 64 lanes on as few pixels as possible, so that its camera and first-bounce rays walk the
+    // same lines (1.31 M triangles: grant 64 is 6 % faster than 256, profiles/r02_sweep_grant_c5.txt).
+    static const uint32_t grant_on_l2[6] = {32u, 64u, 128u, 256u, 256u, 256u};
+    static const uint32_t grant_beyond_l2[6] = {16u, 16u, 32u, 64u, 64u, 64u};
+    const size_t scene_bytes = (size_t)c->bvh.n_nodes * sizeof(ptd::HNode) + (size_t)c->bvh.n_tris * sizeof(ptd::TriRecord);
+    a.grant = (scene_bytes <= ((size_t)4 << 20) ? grant_on_l2 : grant_beyond_l2)[a.chunk_shift];
     a.chunk_spp = p->samplesPerPixel >> a.chunk_shift;
     a.n_frames = n_frames;
     a.sub_shift = a.chunk_shift;

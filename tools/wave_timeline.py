@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--fuse", type=int, default=8)
     ap.add_argument("--chunks", type=int, default=0)
     ap.add_argument("--partition", default="0,1")
-    ap.add_argument("--variant", type=int, default=2)
+    ap.add_argument("--variant", type=int, default=6)
     a = ap.parse_args()
     L = _native.hip()
     state, obj = pt.setup(os.path.join(pt.SCENES, a.scene), width=a.width, height=a.height, max_depth=a.max_depth, direct_lighting=True, importance_sampling=True, spp=a.spp)
