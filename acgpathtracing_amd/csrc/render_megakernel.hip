@@ -42,20 +42,22 @@ extern __shared__ uint32_t lds_dyn[];
 // popcount-prefix and keeps the rest as a reserve, so most refills touch no atomic at all.  Shards are per XCD;
 // drained shards are stolen from round-robin.
 //
-// Fold slots: all runs of one (pixel, sub-frame) are granted to ONE wave (grants are whole groups).  Every group of a grant
-// gets a slot of the wave's scratch when the grant is fetched (popped from the wave's free list in LDS); a lane that
+// Fold slots: all runs of one (pixel, sub-frame) are granted to ONE wave (grants are whole groups).  A group takes a slot
+// of the wave's scratch when its first run is dealt to a lane (popped from the wave's free list in LDS and left in the
+// book for the lanes that get the group's other runs; not when the grant is decoded: a grant of 32 groups would hold 32
+// slots for groups that are not being worked on yet, and the slots in use are what has to stay in the L2); a lane that
 // finishes a run parks its partial sum there and bumps the slot's ticket (an LDS counter, one ds_add_rtn for all the lanes
 // that finish in a round); the lane that brings the ticket to the run count adds the partial sums in run order — the
-// association orc_render(chunks) uses —, writes the sum and pushes the slot back.  Open groups per wave <= 64 lanes
-// in flight + one grant (<= 48 groups), slots 128.
+// association orc_render(chunks) uses —, writes the sum and pushes the slot back.  Open groups per wave <= 64 (one per
+// lane in flight), slots 128.
 constexpr uint32_t kFoldSlots = 128u;
 constexpr uint32_t kNoSlot = 0xFFu;
-constexpr uint32_t kBookDwords = kFoldSlots / 2u + 2u;        // per wave in LDS: tickets and free-slot stack (a byte each), the stack's height
+constexpr uint32_t kBookDwords = kFoldSlots / 2u + 16u;       // per wave in LDS: tickets and free-slot stack (a byte each), slot of each group of the grant (a byte each)
 
 struct WaveBook {
     uint32_t* tick;      // [kFoldSlots / 4] runs parked so far, one byte per slot (<= 32 runs)
     uint8_t*  free;      // [kFoldSlots] stack of free slots
-    uint32_t* top;       // entries on the stack
+    uint8_t*  gslot;     // [64] fold slot of group grant_g0 + j of the current grant, once its first run has been dealt
     // park one more run in `slot`; returns how many were parked before (ds_add_rtn_u32 on the byte's dword)
     __device__ __forceinline__ uint32_t bump(uint32_t slot) const
     { return (atomicAdd(&tick[slot >> 2], 1u << (8u * (slot & 3u))) >> (8u * (slot & 3u))) & 0xFFu; }
@@ -63,17 +65,17 @@ struct WaveBook {
 };
 __device__ __forceinline__ WaveBook wave_book(uint32_t* lds, uint32_t lane)
 {
-    WaveBook b; b.tick = lds; b.free = (uint8_t*)(lds + kFoldSlots / 4u); b.top = lds + kFoldSlots / 2u;
+    WaveBook b; b.tick = lds; b.free = (uint8_t*)(lds + kFoldSlots / 4u); b.gslot = (uint8_t*)(lds + kFoldSlots / 2u);
     if (lane < kFoldSlots / 4u) b.tick[lane] = 0u;
     b.free[lane] = (uint8_t)lane; b.free[64u + lane] = (uint8_t)(64u + lane);
-    if (lane == 0u) *b.top = kFoldSlots;
     return b;
 }
 
 struct QueueState {
     uint32_t shard, shards_left, res_first, res_count;
     uint32_t grant_g0;                    // first group of the current grant
-    uint32_t grp_pxy, grp_seed, grp_slot; // PER LANE: lane j holds pixel (x | y << 16, 0xFFFFFFFF = padding), tea<4> seed and fold slot of group grant_g0 + j
+    uint32_t free_top;                    // entries on the wave's stack of free fold slots (WaveBook::free)
+    uint32_t grp_pxy, grp_seed;           // PER LANE: lane j holds pixel (x | y << 16, 0xFFFFFFFF = padding) and tea<4> seed of group grant_g0 + j
 };
 
 struct LanePixel {
@@ -153,13 +155,6 @@ __device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q,
                 const bool ok = (g << cs) < first + avail && x < A.width && y < A.height && f < A.n_frames;   // else: padding of the tile / batch grid
                 q.grp_pxy = ok ? (x | (y << 16)) : 0xFFFFFFFFu;
                 q.grp_seed = tea4(y * A.width + x, A.frame + f);
-                q.grp_slot = kNoSlot;
-                if (cs != 0u) {   // fold slots for the grant's groups: the n-th real group takes the n-th entry from the top of the free stack
-                    const unsigned long long okm = vote(ok);
-                    const uint32_t top = (uint32_t)__builtin_amdgcn_readfirstlane((int)*book.top);
-                    if (ok) q.grp_slot = (uint32_t)book.free[top - 1u - (uint32_t)popc(okm & below)];
-                    if (lane == 0u) *book.top = top - (uint32_t)popc(okm);
-                }
             }
         }
         const uint32_t want = (uint32_t)popc(idle);
@@ -167,14 +162,27 @@ __device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q,
         const uint32_t rank = (uint32_t)popc(idle & below);
         const uint32_t item = q.res_first + rank;
         {
-            // a lane fetches pixel, seed and fold slot of its group from the lane that decoded it when the grant was taken, and
-            // skips the LCG ahead to its run (one run per group: a skip of zero steps, no slot)
+            // a lane fetches pixel and seed of its group from the lane that decoded it when the grant was taken, and skips the
+            // LCG ahead to its run (one run per group: a skip of zero steps, no slot)
             const uint32_t run = item & run_mask;
-            const int src = (int)(((item >> cs) - q.grant_g0) << 2);           // ds_bpermute takes a byte index
+            const uint32_t gj = (item >> cs) - q.grant_g0;
+            const int src = (int)(gj << 2);                                    // ds_bpermute takes a byte index
             const uint32_t pxy = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)q.grp_pxy);
             const uint32_t seed0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)q.grp_seed);
-            const uint32_t sl = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)q.grp_slot);
-            if (!lp.alive && rank < take && pxy != 0xFFFFFFFFu) {
+            const bool mine = !lp.alive && rank < take && pxy != 0xFFFFFFFFu;
+            uint32_t sl = kNoSlot;
+            if (cs != 0u) {
+                // fold slot of the group: the lane that gets run 0 pops one (the n-th such lane of this deal the n-th entry from
+                // the top of the free stack) and leaves it in the book; runs are dealt in item order, so the lanes with the
+                // group's other runs — in this deal or a later one — find it there (LDS operations of a wave are in order)
+                const unsigned long long opens = vote(mine && run == 0u);
+                if (opens != 0ull) {
+                    if (mine && run == 0u) book.gslot[gj] = book.free[q.free_top - 1u - (uint32_t)popc(opens & below)];
+                    q.free_top -= (uint32_t)popc(opens);
+                }
+                if (mine) sl = (uint32_t)book.gslot[gj];
+            }
+            if (mine) {
                 lp.pxy = pxy;
                 lp.tag = (((item >> cs) & fmask) << cs) | run | (sl << 16);
                 lp.seed = lcg_skip[2u * run] * seed0 + lcg_skip[2u * run + 1u];     // skip the jitter draws of the samples before this run (2 per sample)
@@ -227,7 +235,7 @@ __device__ __forceinline__ void load4_coherent(const float* p, v3f_t& a, v3f_t& 
 // Lanes with `finished` set have completed their run of samples.  One run per pixel: write.  Several: park the partial
 // sum in the group's fold slot, bump the slot's ticket, and the lane that completes the group adds the runs in order.
 // scratch: this wave's (kFoldSlots << chunk_shift) partial sums, three floats each.
-__device__ __forceinline__ void finish_runs(const RenderArgs& A, const LanePixel& lp, bool finished, const WaveBook& book, float* __restrict__ scratch)
+__device__ __forceinline__ void finish_runs(const RenderArgs& A, QueueState& q, unsigned long long below, const LanePixel& lp, bool finished, const WaveBook& book, float* __restrict__ scratch)
 {
     if (vote(finished) == 0ull) return;
     const uint32_t cs = A.chunk_shift, runs = 1u << cs;
@@ -244,7 +252,8 @@ __device__ __forceinline__ void finish_runs(const RenderArgs& A, const LanePixel
         mine[0] = lp.result.x; mine[1] = lp.result.y; mine[2] = lp.result.z;
         folder = book.bump(slot) == runs - 1u;                       // LDS: lanes of one group that finish together get distinct counts
     }
-    if (vote(folder) == 0ull) return;
+    const unsigned long long folders = vote(folder);
+    if (folders == 0ull) return;
     // the partial sums were stored by lanes of this wave through this CU's L1: wait for the stores, then read them back
     // past the L1 (sc0 loads), whatever lines an earlier use of the slot left there
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -269,8 +278,9 @@ __device__ __forceinline__ void finish_runs(const RenderArgs& A, const LanePixel
         }
         write_frame_sum(A, pixel_index(A, lp), sub >> cs, sum);
         book.clear(slot);
-        book.free[atomicAdd(book.top, 1u)] = (uint8_t)slot;          // back on the free stack
+        book.free[q.free_top + (uint32_t)popc(folders & below)] = (uint8_t)slot;          // back on the free stack
     }
+    q.free_top += (uint32_t)popc(folders);
 }
 
 // frame batches: for every pixel of this rank, blend the sub-frames' sums into the accumulation buffer in frame order —
@@ -343,7 +353,7 @@ k_render(const RenderArgsBox B)
     const float fw = (float)(int)A.width, fh = (float)(int)A.height;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-    QueueState q; q.shard = xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.grant_g0 = 0; q.grp_pxy = 0xFFFFFFFFu; q.grp_seed = 0; q.grp_slot = kNoSlot;
+    QueueState q; q.shard = xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.grant_g0 = 0; q.grp_pxy = 0xFFFFFFFFu; q.grp_seed = 0; q.free_top = kFoldSlots;
     unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0;
     float* const scratch = A.wave_scratch + 3u * (size_t)(blockIdx.x * (kRenderThreads / 64) + wave) * ((size_t)kFoldSlots << A.chunk_shift);
 
@@ -408,7 +418,7 @@ k_render(const RenderArgsBox B)
         }
         n_paths += (unsigned long long)popc(vote(end));
         n_pixels += (unsigned long long)popc(vote(finished));
-        finish_runs(A, lp, finished, book, scratch);
+        finish_runs(A, q, below, lp, finished, book, scratch);
     }
     if (lane == 0) {
         atomicAdd(&A.counters[0], n_radiance);
@@ -509,7 +519,7 @@ k_render_pw(const RenderArgsBox B)
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int root = sc.n_tris ? 0 : kSentinel;
 
-    QueueState q; q.shard = xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.grant_g0 = 0; q.grp_pxy = 0xFFFFFFFFu; q.grp_seed = 0; q.grp_slot = kNoSlot;
+    QueueState q; q.shard = xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.grant_g0 = 0; q.grp_pxy = 0xFFFFFFFFu; q.grp_seed = 0; q.free_top = kFoldSlots;
     float* const scratch = A.wave_scratch + 3u * (size_t)(blockIdx.x * (THREADS / 64) + wave) * ((size_t)kFoldSlots << A.chunk_shift);
     unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0;
     unsigned long long n_steps = 0, n_lane_steps = 0, n_rounds = 0, n_lane_rounds = 0;
@@ -593,7 +603,7 @@ k_render_pw(const RenderArgsBox B)
         fin_pending = false;
         n_pixels += (unsigned long long)popc(vote(finished));
         if (STATS) t_mark = __builtin_amdgcn_s_memrealtime();
-        finish_runs(A, lp, finished, book, scratch);     // before the refill overwrites the lanes' items
+        finish_runs(A, q, below, lp, finished, book, scratch);     // before the refill overwrites the lanes' items
         if (STATS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); t_finish += now - t_mark; t_mark = now; }
 
         refill_lanes<STATS>(A, q, lane, below, lp, lcg_skip, book);
