@@ -505,9 +505,11 @@ __device__ __forceinline__ uint32_t half_bits(__half h) { return (uint32_t)__hal
 __device__ __forceinline__ uint32_t pack_planes(float lo, float hi, float c, float scale, float& glo, float& ghi)
 {
     if (!(lo <= hi)) { glo = 0.0f; ghi = 0.0f; return 0x7C00u | (0xFC00u << 16); }      // empty child: lo = +inf, hi = -inf
-    // (w - c) * scale rounds twice in fp32; one extra fp16 step outward covers that
+    // (w - c) * scale rounds twice in fp32 (2^-23 of the coordinate), and the render kernel's plane multiplier carries the ray's
+    // rotate flags in its five lowest mantissa bits (setup_ray, NODE_FMT 9: 2^-19 of the coordinate): each plane goes outward
+    // by 2^-18 of its own coordinate before it is rounded outward to fp16 (whose step is 2^-11 of it)
     const float a = (lo - c) * scale, b = (hi - c) * scale;
-    __half hl = __float2half_rd(a - fabsf(a) * 2e-7f), hh = __float2half_ru(b + fabsf(b) * 2e-7f);
+    __half hl = __float2half_rd(a - fabsf(a) * 3.9e-6f), hh = __float2half_ru(b + fabsf(b) * 3.9e-6f);
     glo = __half2float(hl); ghi = __half2float(hh);
     return half_bits(hl) | (half_bits(hh) << 16);
 }

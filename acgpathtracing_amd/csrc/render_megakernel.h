@@ -61,7 +61,7 @@ int render_variant_count();
 const char* render_variant_name(int variant);
 int render_variant_threads(int variant);
 int render_variant_stack_cap(int variant);      // 0 = the whole stack in LDS
-int render_variant_node_format(int variant);   // 0 fp32 two-child, 7 fp16 two-child; experiments: 1/2/4 16-bit grid, 3 four-wide 8-bit
+int render_variant_node_format(int variant);   // 0 fp32 two-child; 7 / 8 / 9 fp16 two-child (min-max / rotated / rotated, flags in the multipliers); experiments: 1/2/4 16-bit grid, 3 four-wide 8-bit
 hipError_t render_occupancy(int variant, uint32_t stack_entries, uint32_t n_nodes, int* blocks_per_cu);
 hipError_t launch_render(int variant, const RenderArgs& args, uint32_t grid_blocks, hipStream_t stream);
 hipError_t launch_finalize(const RenderArgs& args, hipStream_t stream);

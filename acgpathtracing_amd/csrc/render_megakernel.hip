@@ -446,10 +446,19 @@ __device__ __forceinline__ void setup_ray(const f3& ro, const f3& rd, const QGri
     if (NODE_FMT == 0 || NODE_FMT == 6) {            // t = p * (1/d) + (-o/d)
         rinv = mk(finite_rcp(rd.x), finite_rcp(rd.y), finite_rcp(rd.z));
         gro = mk(-(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z));
-    } else if (NODE_FMT == 7 || NODE_FMT == 8) {     // t = g * (1/d / scale) + (centre - o)/d, g = the fp16 plane
+    } else if (NODE_FMT == 7 || NODE_FMT == 8 || NODE_FMT == 9) {     // t = g * (1/d / scale) + (centre - o)/d, g = the fp16 plane
         const f3 r = mk(finite_rcp(rd.x), finite_rcp(rd.y), finite_rcp(rd.z));
         gro = mk((HS.cx - ro.x) * r.x, (HS.cy - ro.y) * r.y, (HS.cz - ro.z) * r.z);
         rinv = r * HS.inv_scale;
+        if (NODE_FMT == 9) {
+            // the rotate amount of NODE_FMT 8 (16 where the ray runs against the axis, else 0) rides in the multiplier's own
+            // five lowest mantissa bits — v_alignbit_b32 reads just those — so it costs no register.  That moves the multiplier
+            // by at most 31 ulp (2^-19 relative), i.e. a plane by 2^-19 of its own coordinate; pack_planes() rounds every fp16
+            // plane outward by 2^-18 of its coordinate for it.
+            rinv.x = __uint_as_float((__float_as_uint(rinv.x) & ~31u) | (r.x < 0.0f ? 16u : 0u));
+            rinv.y = __uint_as_float((__float_as_uint(rinv.y) & ~31u) | (r.y < 0.0f ? 16u : 0u));
+            rinv.z = __uint_as_float((__float_as_uint(rinv.z) & ~31u) | (r.z < 0.0f ? 16u : 0u));
+        }
     } else {
         rinv = mk(fast_rcp(rd.x), fast_rcp(rd.y), fast_rcp(rd.z));
         if (NODE_FMT == 1 || NODE_FMT == 2 || NODE_FMT == 4) {
@@ -472,8 +481,12 @@ __device__ __forceinline__ void setup_ray(const f3& ro, const f3& rd, const QGri
 // =================================================================================================
 // NODE_FMT: 0 = fp32 boxes, 64-byte nodes in global memory (4 x 16-byte loads per visit), slab test as one fma per plane
 //           7 = fp16 boxes in a scene-centred space, 32-byte nodes (2 loads per visit), the same fma count: each plane is a
-//               v_fma_mix_f32 reading the fp16 half in place (pt_device.h HNode)
-//           5 = the same nodes, slab test as subtract + multiply per plane
+//               v_fma_mix_f32 reading the fp16 half in place (pt_device.h HNode), near / far by per-axis min / max
+//           8 = the same nodes; each packed {lo, hi} pair is rotated by 0 or 16 bits first (v_alignbit_b32, per ray and axis),
+//               so the low half is the near plane: 6 rotates replace 12 min / max; three registers of rotate amounts
+//           9 = the same, with the rotate amount in the five lowest mantissa bits of the plane multiplier (setup_ray): no
+//               register for it — the default
+//           5 = the fp32 nodes, slab test as subtract + multiply per plane
 //           4 = 16-bit grid nodes with the fma form
 //           1 = 16-bit grid boxes, 32-byte nodes in global memory (2 loads per visit)
 //           2 = the same 32-byte nodes staged into LDS by each workgroup (scenes whose node array
@@ -770,6 +783,18 @@ k_render_pw(const RenderArgsBox B)
                     n0 = fmaxf(fmaxf(fma_h_lo(ax, rinv.x, gro.x), fma_h_lo(ay, rinv.y, gro.y)), fmaxf(fma_h_lo(az, rinv.z, gro.z), rtmin));
                     f0 = fminf(fminf(fma_h_hi(ax, rinv.x, gro.x), fma_h_hi(ay, rinv.y, gro.y)), fma_h_hi(az, rinv.z, gro.z)) * kFarWiden;
                     const uint32_t bx = rot16(qb.x, rot.x), by = rot16(qb.y, rot.y), bz = rot16(qb.z, rot.z);
+                    n1 = fmaxf(fmaxf(fma_h_lo(bx, rinv.x, gro.x), fma_h_lo(by, rinv.y, gro.y)), fmaxf(fma_h_lo(bz, rinv.z, gro.z), rtmin));
+                    f1 = fminf(fminf(fma_h_hi(bx, rinv.x, gro.x), fma_h_hi(by, rinv.y, gro.y)), fma_h_hi(bz, rinv.z, gro.z)) * kFarWiden;
+                } else if (NODE_FMT == 9) {
+                    // NODE_FMT 8 with the rotate amounts read from the low bits of the plane multipliers (setup_ray)
+                    const uint4* np = (const uint4*)((const char*)sc.hnodes + (size_t)((uint32_t)node << 5));
+                    const uint4 qa = np[0], qb = np[1];
+                    c0 = (int)qa.w; c1 = (int)qb.w;
+                    const uint32_t rx = __float_as_uint(rinv.x), ry = __float_as_uint(rinv.y), rz = __float_as_uint(rinv.z);
+                    const uint32_t ax = rot16(qa.x, rx), ay = rot16(qa.y, ry), az = rot16(qa.z, rz);
+                    n0 = fmaxf(fmaxf(fma_h_lo(ax, rinv.x, gro.x), fma_h_lo(ay, rinv.y, gro.y)), fmaxf(fma_h_lo(az, rinv.z, gro.z), rtmin));
+                    f0 = fminf(fminf(fma_h_hi(ax, rinv.x, gro.x), fma_h_hi(ay, rinv.y, gro.y)), fma_h_hi(az, rinv.z, gro.z)) * kFarWiden;
+                    const uint32_t bx = rot16(qb.x, rx), by = rot16(qb.y, ry), bz = rot16(qb.z, rz);
                     n1 = fmaxf(fmaxf(fma_h_lo(bx, rinv.x, gro.x), fma_h_lo(by, rinv.y, gro.y)), fmaxf(fma_h_lo(bz, rinv.z, gro.z), rtmin));
                     f1 = fminf(fminf(fma_h_hi(bx, rinv.x, gro.x), fma_h_hi(by, rinv.y, gro.y)), fma_h_hi(bz, rinv.z, gro.z)) * kFarWiden;
                 } else if (NODE_FMT == 6) {
@@ -1283,10 +1308,10 @@ static const VariantDesc kVariants[] = {
     {k_render_pw<48, 8, 0, 256, 4, false, 0, 2>, 256, 0, "pw K48 L8 fp32 nodes w4, two visits per loop trip (large scenes whose fp16 planes would be too coarse)"},
     {k_render_pw<48, 12, 0, 256, 4, false, 3, 1>, 256, 0, "FAST-MATH hardware sin/cos + algebraic acos in the cosine-weighted sampler (opt-in; other bits than the default)"},
     {k_render_pw<44, 16, 8, 256, 4, false, 0, 3, 2>, 256, 8, "pw K44 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes, w4, three visits and two triangle tests per loop trip"},
-    {k_render_pw<44, 16, 8, 256, 4, true, 0, 3, 2>, 256, 8, "pw K44 L16 fp16 sign-rotated nodes + scheduler stats"},
-    {k_render_pw<44, 16, 7, 256, 5, false, 0, 3, 2>, 256, 7, "pw K44 L16 fp16 nodes (32 B), v_fma_mix planes with per-axis min / max, FIVE waves per SIMD (96 registers), three visits and two triangle tests per loop trip"},
+    {k_render_pw<44, 16, 9, 256, 4, true, 0, 5, 2>, 256, 9, "pw K44 L16 fp16 sign-rotated nodes, five visits per trip + scheduler stats (the default kernel's loop at four waves)"},
+    {k_render_pw<44, 16, 9, 256, 5, false, 0, 5, 2>, 256, 9, "pw K44 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes with the rotate amounts in the multipliers' low bits, FIVE waves per SIMD (96 registers), five visits and two triangle tests per loop trip"},
     {k_render_pw<44, 16, 8, 256, 4, false, 0, 3, 2, true>, 256, 8, "LIGHTS scene-driven area lights + MIS (light mode 1, opt-in: not the reference's estimator), fp16 sign-rotated nodes w4"},
-    {k_render_pw<44, 16, 7, 256, 5, false, 0, 3, 2, false, 28>, 256, 7, "pw K44 L16 fp16 nodes, five waves per SIMD for deep trees: 28 stack entries per lane in LDS, deeper ones in global memory", 28},
+    {k_render_pw<44, 16, 9, 256, 5, false, 0, 5, 2, false, 28>, 256, 9, "pw K44 L16 fp16 sign-rotated nodes, five waves per SIMD for deep trees: 28 stack entries per lane in LDS, deeper ones in global memory", 28},
 #ifdef ACGPT_EXPERIMENTS
     {k_render_pw<40, 8, 0, 256, 4, false, 0, 1>, 256, 0, "pw K40 L8 fp32 w4, register stack top"},
     {k_render_pw<48, 8, 0, 256, 4, false>, 256, 0, "pw K48 L8 fp32 w4, LDS-only stack"},
@@ -1337,6 +1362,25 @@ static const VariantDesc kVariants[] = {
     {k_render_pw<44, 16, 6, 256, 5, false, 0, 2, 2>, 256, 0, "pw K44 L16 fp32 centre / half-extent V2 T2 w5"},
     {k_render_pw<48, 16, 8, 256, 5, false, 0, 2, 2>, 256, 8, "pw K48 L16 fp16 sign-rotated V2 T2 w5"},
     {k_render_pw<40, 16, 8, 256, 5, false, 0, 2, 2>, 256, 8, "pw K40 L16 fp16 sign-rotated V2 T2 w5"},
+    {k_render_pw<44, 16, 9, 256, 5, false, 0, 3, 2>, 256, 9, "pw K44 L16 fp16 sign-rotated, rotate amounts in the multipliers' low bits, V3 T2 w5"},
+    {k_render_pw<44, 16, 9, 256, 4, false, 0, 3, 2>, 256, 9, "pw K44 L16 fp16 sign-rotated, rotate amounts in the multipliers' low bits, V3 T2 w4"},
+    {k_render_pw<44, 16, 9, 256, 5, false, 0, 3, 2, false, 28>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) w5, 28 stack entries in LDS", 28},
+    {k_render_pw<44, 16, 9, 256, 5, false, 0, 2, 2>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) V2 T2 w5"},
+    {k_render_pw<44, 16, 9, 256, 5, false, 0, 4, 2>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) V4 T2 w5"},
+    {k_render_pw<40, 16, 9, 256, 5, false, 0, 3, 2>, 256, 9, "pw K40 L16 fp16 sign-rotated (low bits) V3 T2 w5"},
+    {k_render_pw<48, 16, 9, 256, 5, false, 0, 3, 2>, 256, 9, "pw K48 L16 fp16 sign-rotated (low bits) V3 T2 w5"},
+    {k_render_pw<44, 12, 9, 256, 5, false, 0, 3, 2>, 256, 9, "pw K44 L12 fp16 sign-rotated (low bits) V3 T2 w5"},
+    {k_render_pw<44, 20, 9, 256, 5, false, 0, 3, 2>, 256, 9, "pw K44 L20 fp16 sign-rotated (low bits) V3 T2 w5"},
+    {k_render_pw<44, 16, 9, 256, 5, false, 0, 3, 3>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) V3 T3 w5"},
+    {k_render_pw<44, 16, 9, 256, 5, false, 0, 3, 1>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) V3 T1 w5"},
+    {k_render_pw<44, 16, 9, 256, 6, false, 0, 3, 2>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) V3 T2 w6"},
+    {k_render_pw<44, 16, 9, 256, 5, false, 0, 4, 2, false, 28>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) V4 T2 w5, 28 stack entries in LDS", 28},
+    {k_render_pw<44, 16, 7, 256, 5, false, 0, 3, 2>, 256, 7, "pw K44 L16 fp16 min / max V3 T2 w5 (the default before the rotate amounts moved into the multipliers)"},
+    {k_render_pw<44, 16, 9, 256, 5, false, 0, 6, 2>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) V6 T2 w5"},
+    {k_render_pw<44, 16, 9, 256, 5, false, 0, 8, 2>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) V8 T2 w5"},
+    {k_render_pw<44, 16, 9, 256, 5, false, 0, 5, 3>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) V5 T3 w5"},
+    {k_render_pw<44, 16, 7, 256, 5, false, 0, 3, 2, false, 28>, 256, 7, "pw K44 L16 fp16 min / max V3 T2 w5, 28 stack entries in LDS", 28},
+    {k_render_pw<44, 16, 7, 256, 5, false, 0, 5, 2>, 256, 7, "pw K44 L16 fp16 min / max V5 T2 w5"},
 #endif
 };
 int render_variant_count() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
