@@ -1310,7 +1310,7 @@ static const VariantDesc kVariants[] = {
     {k_render_pw<44, 16, 8, 256, 4, false, 0, 3, 2>, 256, 8, "pw K44 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes, w4, three visits and two triangle tests per loop trip"},
     {k_render_pw<44, 16, 9, 256, 4, true, 0, 5, 2>, 256, 9, "pw K44 L16 fp16 sign-rotated nodes, five visits per trip + scheduler stats (the default kernel's loop at four waves)"},
     {k_render_pw<44, 16, 9, 256, 5, false, 0, 5, 2>, 256, 9, "pw K44 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes with the rotate amounts in the multipliers' low bits, FIVE waves per SIMD (96 registers), five visits and two triangle tests per loop trip"},
-    {k_render_pw<44, 16, 8, 256, 4, false, 0, 3, 2, true>, 256, 8, "LIGHTS scene-driven area lights + MIS (light mode 1, opt-in: not the reference's estimator), fp16 sign-rotated nodes w4"},
+    {k_render_pw<44, 16, 9, 256, 4, false, 0, 5, 2, true>, 256, 9, "LIGHTS scene-driven area lights + MIS (light mode 1, opt-in: not the reference's estimator), fp16 sign-rotated nodes w4"},
     {k_render_pw<44, 16, 9, 256, 5, false, 0, 5, 2, false, 28>, 256, 9, "pw K44 L16 fp16 sign-rotated nodes, five waves per SIMD for deep trees: 28 stack entries per lane in LDS, deeper ones in global memory", 28},
 #ifdef ACGPT_EXPERIMENTS
     {k_render_pw<40, 8, 0, 256, 4, false, 0, 1>, 256, 0, "pw K40 L8 fp32 w4, register stack top"},
