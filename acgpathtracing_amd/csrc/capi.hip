@@ -647,8 +647,8 @@ PT_API int pt_bench_traversal(pt_ctx* c, const float* rays, size_t n, int repeat
 // in / out sizes per element, in dwords (op 1: in = {seed, count}, out = 2 * count)
 PT_API int pt_selftest(pt_ctx* c, int op, const void* in, size_t n, void* out)
 {
-    static const int in_dw[19] = {2, 2, 3, 10, 10, 10, 10, 10, 10, 7, 4, 1, 6, 4, 2, 2, 6, 7, 3}, out_dw[19] = {1, 0, 1, 3, 3, 3, 3, 3, 3, 4, 2, 4, 3, 3, 3, 3, 3, 3, 1};
-    if (!c || !in || !out || op < 0 || op > 18 || n == 0 || n > (1u << 24)) return fail(c, "pt_selftest: bad argument");
+    static const int in_dw[20] = {2, 2, 3, 10, 10, 10, 10, 10, 10, 7, 4, 1, 6, 4, 2, 2, 6, 7, 3, 17}, out_dw[20] = {1, 0, 1, 3, 3, 3, 3, 3, 3, 4, 2, 4, 3, 3, 3, 3, 3, 3, 1, 3};
+    if (!c || !in || !out || op < 0 || op > 19 || n == 0 || n > (1u << 24)) return fail(c, "pt_selftest: bad argument");
     CK(c, hipSetDevice(c->device));
     size_t in_bytes = n * (size_t)in_dw[op] * 4, out_bytes = n * (size_t)out_dw[op] * 4;
     uint32_t launch_n = (uint32_t)n;

@@ -501,18 +501,6 @@ __global__ void k_centre_nodes(const BvhNode* __restrict__ nodes, uint32_t n, Bv
 // Planes go to the scene-centred, power-of-two scaled space of HSpace and are rounded OUTWARD to fp16 (lo down, hi up),
 // so every fp16 box contains its fp32 box.  area[0] / area[1] accumulate the child-box surface areas before / after,
 // the measure by which pt_set_scene decides whether the coarser planes are acceptable for this scene.
-__device__ __forceinline__ uint32_t half_bits(__half h) { return (uint32_t)__half_as_ushort(h); }
-__device__ __forceinline__ uint32_t pack_planes(float lo, float hi, float c, float scale, float& glo, float& ghi)
-{
-    if (!(lo <= hi)) { glo = 0.0f; ghi = 0.0f; return 0x7C00u | (0xFC00u << 16); }      // empty child: lo = +inf, hi = -inf
-    // (w - c) * scale rounds twice in fp32 (2^-23 of the coordinate), and the render kernel's plane multiplier carries the ray's
-    // rotate flags in its five lowest mantissa bits (setup_ray, NODE_FMT 9: 2^-19 of the coordinate): each plane goes outward
-    // by 2^-18 of its own coordinate before it is rounded outward to fp16 (whose step is 2^-11 of it)
-    const float a = (lo - c) * scale, b = (hi - c) * scale;
-    __half hl = __float2half_rd(a - fabsf(a) * 3.9e-6f), hh = __float2half_ru(b + fabsf(b) * 3.9e-6f);
-    glo = __half2float(hl); ghi = __half2float(hh);
-    return half_bits(hl) | (half_bits(hh) << 16);
-}
 __global__ void k_half_nodes(const BvhNode* __restrict__ nodes, uint32_t n, HSpace sp, HNode* __restrict__ hn, float* __restrict__ area)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

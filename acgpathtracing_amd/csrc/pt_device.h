@@ -13,6 +13,7 @@
 // tri_test(), which must match oracle/oracle_pt.cpp bit for bit.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 #include "../../include/acgpt.h"
 
@@ -206,6 +207,44 @@ __device__ __forceinline__ float finite_rcp(float x) { return fminf(fmaxf(__buil
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float fma_h_lo(uint32_t packed, float a, float b) { return __builtin_fmaf((float)__builtin_bit_cast(half2_t, packed).x, a, b); }
 __device__ __forceinline__ float fma_h_hi(uint32_t packed, float a, float b) { return __builtin_fmaf((float)__builtin_bit_cast(half2_t, packed).y, a, b); }
+
+// ---- the slab test of the default render kernel on fp16 planes (NODE_FMT 9 of render_megakernel.hip) ----
+// pack_planes: builder side.  Planes go to the scene-centred, power-of-two scaled space of HSpace and are rounded OUTWARD.
+__device__ __forceinline__ uint32_t half_bits(__half h) { return (uint32_t)__half_as_ushort(h); }
+__device__ __forceinline__ uint32_t pack_planes(float lo, float hi, float c, float scale, float& glo, float& ghi)
+{
+    if (!(lo <= hi)) { glo = 0.0f; ghi = 0.0f; return 0x7C00u | (0xFC00u << 16); }      // empty child: lo = +inf, hi = -inf
+    // (w - c) * scale rounds twice in fp32 (2^-23 of the coordinate), and the render kernel's plane multiplier carries the ray's
+    // rotate flags in its five lowest mantissa bits (setup_ray, NODE_FMT 9: 2^-19 of the coordinate): each plane goes outward
+    // by 2^-18 of its own coordinate before it is rounded outward to fp16 (whose step is 2^-11 of it)
+    const float a = (lo - c) * scale, b = (hi - c) * scale;
+    __half hl = __float2half_rd(a - fabsf(a) * 3.9e-6f), hh = __float2half_ru(b + fabsf(b) * 3.9e-6f);
+    glo = __half2float(hl); ghi = __half2float(hh);
+    return half_bits(hl) | (half_bits(hh) << 16);
+}
+
+// Per-ray constants: t = g * mul + add for an fp16 plane g, mul = (1/d) / scale, add = (centre - o) / d.  The five lowest
+// mantissa bits of mul carry the rotate amount of its axis — 16 where the ray runs against the axis, else 0 —, which is all
+// v_alignbit_b32 reads of its shift operand: the packed {lo, hi} pair of a node is rotated so that its low half is the plane
+// the ray meets first, and near / far need no per-axis min / max and no register for the amounts.  Forcing those bits moves
+// mul by at most 31 ulp (2^-19 relative), i.e. a plane by 2^-19 of its own coordinate; pack_planes() pads by 2^-18 of it.
+__device__ __forceinline__ void setup_ray_h9(const f3& ro, const f3& rd, const HSpace& HS, f3& mul, f3& add)
+{
+    const f3 r = mk(finite_rcp(rd.x), finite_rcp(rd.y), finite_rcp(rd.z));
+    add = mk((HS.cx - ro.x) * r.x, (HS.cy - ro.y) * r.y, (HS.cz - ro.z) * r.z);
+    mul = r * HS.inv_scale;
+    mul.x = __uint_as_float((__float_as_uint(mul.x) & ~31u) | (r.x < 0.0f ? 16u : 0u));
+    mul.y = __uint_as_float((__float_as_uint(mul.y) & ~31u) | (r.y < 0.0f ? 16u : 0u));
+    mul.z = __uint_as_float((__float_as_uint(mul.z) & ~31u) | (r.z < 0.0f ? 16u : 0u));
+}
+__device__ __forceinline__ uint32_t rot16(uint32_t v, uint32_t by) { return __builtin_amdgcn_alignbit(v, v, by); }
+// entry and exit distance of one child box {px, py, pz} (packed {lo, hi} per axis): 3 rotates, 6 v_fma_mix_f32, max3 / min3
+__device__ __forceinline__ void slab_h9(uint32_t px, uint32_t py, uint32_t pz, const f3& mul, const f3& add, float rtmin, float& tn, float& tf)
+{
+    const uint32_t ax = rot16(px, __float_as_uint(mul.x)), ay = rot16(py, __float_as_uint(mul.y)), az = rot16(pz, __float_as_uint(mul.z));
+    tn = fmaxf(fmaxf(fma_h_lo(ax, mul.x, add.x), fma_h_lo(ay, mul.y, add.y)), fmaxf(fma_h_lo(az, mul.z, add.z), rtmin));
+    tf = fminf(fminf(fma_h_hi(ax, mul.x, add.x), fma_h_hi(ay, mul.y, add.y)), fma_h_hi(az, mul.z, add.z)) * kFarWiden;
+}
 
 // ------------------------------------------------------------ wave votes ----
 // __ballot(int) first turns the predicate into 0 / 1 in a VGPR and compares it again (two half-rate vector

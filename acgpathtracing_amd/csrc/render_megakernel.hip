@@ -438,7 +438,6 @@ __device__ __forceinline__ AxisRot axis_rot(const f3& rinv)
     r.x = rinv.x < 0.0f ? 16u : 0u; r.y = rinv.y < 0.0f ? 16u : 0u; r.z = rinv.z < 0.0f ? 16u : 0u;
     return r;
 }
-__device__ __forceinline__ uint32_t rot16(uint32_t v, uint32_t by) { return __builtin_amdgcn_alignbit(v, v, by); }
 
 template <int NODE_FMT>
 __device__ __forceinline__ void setup_ray(const f3& ro, const f3& rd, const QGrid& G, const HSpace& HS, f3& rinv, f3& gro)
@@ -446,19 +445,12 @@ __device__ __forceinline__ void setup_ray(const f3& ro, const f3& rd, const QGri
     if (NODE_FMT == 0 || NODE_FMT == 6) {            // t = p * (1/d) + (-o/d)
         rinv = mk(finite_rcp(rd.x), finite_rcp(rd.y), finite_rcp(rd.z));
         gro = mk(-(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z));
-    } else if (NODE_FMT == 7 || NODE_FMT == 8 || NODE_FMT == 9) {     // t = g * (1/d / scale) + (centre - o)/d, g = the fp16 plane
+    } else if (NODE_FMT == 9) {                      // the same with the rotate amounts in the multipliers (pt_device.h)
+        setup_ray_h9(ro, rd, HS, rinv, gro);
+    } else if (NODE_FMT == 7 || NODE_FMT == 8) {     // t = g * (1/d / scale) + (centre - o)/d, g = the fp16 plane
         const f3 r = mk(finite_rcp(rd.x), finite_rcp(rd.y), finite_rcp(rd.z));
         gro = mk((HS.cx - ro.x) * r.x, (HS.cy - ro.y) * r.y, (HS.cz - ro.z) * r.z);
         rinv = r * HS.inv_scale;
-        if (NODE_FMT == 9) {
-            // the rotate amount of NODE_FMT 8 (16 where the ray runs against the axis, else 0) rides in the multiplier's own
-            // five lowest mantissa bits — v_alignbit_b32 reads just those — so it costs no register.  That moves the multiplier
-            // by at most 31 ulp (2^-19 relative), i.e. a plane by 2^-19 of its own coordinate; pack_planes() rounds every fp16
-            // plane outward by 2^-18 of its coordinate for it.
-            rinv.x = __uint_as_float((__float_as_uint(rinv.x) & ~31u) | (r.x < 0.0f ? 16u : 0u));
-            rinv.y = __uint_as_float((__float_as_uint(rinv.y) & ~31u) | (r.y < 0.0f ? 16u : 0u));
-            rinv.z = __uint_as_float((__float_as_uint(rinv.z) & ~31u) | (r.z < 0.0f ? 16u : 0u));
-        }
     } else {
         rinv = mk(fast_rcp(rd.x), fast_rcp(rd.y), fast_rcp(rd.z));
         if (NODE_FMT == 1 || NODE_FMT == 2 || NODE_FMT == 4) {
@@ -790,13 +782,8 @@ k_render_pw(const RenderArgsBox B)
                     const uint4* np = (const uint4*)((const char*)sc.hnodes + (size_t)((uint32_t)node << 5));
                     const uint4 qa = np[0], qb = np[1];
                     c0 = (int)qa.w; c1 = (int)qb.w;
-                    const uint32_t rx = __float_as_uint(rinv.x), ry = __float_as_uint(rinv.y), rz = __float_as_uint(rinv.z);
-                    const uint32_t ax = rot16(qa.x, rx), ay = rot16(qa.y, ry), az = rot16(qa.z, rz);
-                    n0 = fmaxf(fmaxf(fma_h_lo(ax, rinv.x, gro.x), fma_h_lo(ay, rinv.y, gro.y)), fmaxf(fma_h_lo(az, rinv.z, gro.z), rtmin));
-                    f0 = fminf(fminf(fma_h_hi(ax, rinv.x, gro.x), fma_h_hi(ay, rinv.y, gro.y)), fma_h_hi(az, rinv.z, gro.z)) * kFarWiden;
-                    const uint32_t bx = rot16(qb.x, rx), by = rot16(qb.y, ry), bz = rot16(qb.z, rz);
-                    n1 = fmaxf(fmaxf(fma_h_lo(bx, rinv.x, gro.x), fma_h_lo(by, rinv.y, gro.y)), fmaxf(fma_h_lo(bz, rinv.z, gro.z), rtmin));
-                    f1 = fminf(fminf(fma_h_hi(bx, rinv.x, gro.x), fma_h_hi(by, rinv.y, gro.y)), fma_h_hi(bz, rinv.z, gro.z)) * kFarWiden;
+                    slab_h9(qa.x, qa.y, qa.z, rinv, gro, rtmin, n0, f0);
+                    slab_h9(qb.x, qb.y, qb.z, rinv, gro, rtmin, n1, f1);
                 } else if (NODE_FMT == 6) {
                     // centre / half-extent nodes: near = (c - o)/d - h/|d|, far = (c - o)/d + h/|d|: full-rate arithmetic only,
                     // the |.| is a source modifier

@@ -71,6 +71,23 @@ __global__ void k_selftest(int op, const uint32_t* __restrict__ in, uint32_t n, 
         fout[3 * i] = o.x; fout[3 * i + 1] = o.y; fout[3 * i + 2] = o.z;
         return;
     }
+    if (op == 19) {
+        // the default kernel's box test end to end: in = ray o xyz, d xyz, box lo xyz, hi xyz (fp32, as the builder holds it),
+        // scene centre xyz, inv_scale (a power of two), tmax; out = accepted (n <= min(f, tmax)), n, f.  The box goes through
+        // pack_planes() (outward to fp16), the ray through setup_ray_h9(), the test is slab_h9() — what k_render_pw executes.
+        const float* r = fin + 17 * i;
+        HSpace hs; hs.cx = r[12]; hs.cy = r[13]; hs.cz = r[14]; hs.inv_scale = r[15];
+        const float scale = 1.0f / hs.inv_scale;
+        float gl, gh;
+        const uint32_t px = pack_planes(r[6], r[9], hs.cx, scale, gl, gh), py = pack_planes(r[7], r[10], hs.cy, scale, gl, gh),
+                       pz = pack_planes(r[8], r[11], hs.cz, scale, gl, gh);
+        f3 mul, add;
+        setup_ray_h9(mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5]), hs, mul, add);
+        float tn, tf;
+        slab_h9(px, py, pz, mul, add, 0.01f, tn, tf);
+        out[3 * i] = tn <= fminf(tf, r[16]) ? 1u : 0u; fout[3 * i + 1] = tn; fout[3 * i + 2] = tf;
+        return;
+    }
     if (op == 10) {                                  // in: world, width, rank, sample; out: x, y
         const int* r = (const int*)in + 4 * i;
         int x, y;

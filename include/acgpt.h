@@ -255,7 +255,12 @@ int pt_bench_traversal(pt_ctx* ctx, const float* rays, size_t n, int repeats, in
  *   op 15 uniform_sample_hemisphere (:368-380)                      in float[n][2] = u1, u2          out float[n][3]
  *   op 16 sampleGGX (:455-476)                                      in float[n][6] = u1, u2, roughness, N   out float[n][3]
  *   op 17 fresnelSchlickConductor (:494-510)                        in float[n][7] = cosTheta, eta, k       out float[n][3]
- *   op 18 FrDielectric (:534-559)                                   in float[n][3] = cosThetaI, etaI, etaT  out float[n][1] */
+ *   op 18 FrDielectric (:534-559)                                   in float[n][3] = cosThetaI, etaI, etaT  out float[n][1]
+ * and the default kernel's own ray / box test (no reference counterpart: OptiX traverses there), end to end:
+ *   op 19 fp16 slab test: box -> outward fp16 planes, ray -> per-axis multiplier / addend with the rotate flags in the
+ *         multiplier's low bits, entry / exit distance          in float[n][17] = ray o, d, box lo, hi, scene centre, inv_scale
+ *         (a power of two), tmax    out uint32[n][3] = accepted, entry t (float bits), exit t (float bits).  Must accept every
+ *         ray that meets the box shrunk by the builder's pad (tests/test_gpu_golden.py).                                       */
 int pt_selftest(pt_ctx* ctx, int op, const void* in, size_t n, void* out);
 /* Diagnostic: after a launch of a "+ scheduler stats" kernel variant, three 100 MHz stamps per wave (start,
  * first time it found the work queue empty, end; 0 = wave did not run), HOST output of 3 * max_waves values. */

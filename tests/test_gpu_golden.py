@@ -150,3 +150,71 @@ def test_gpu_ptprog_math(ctx):
         assert same_bits_or_both_nan(got[~ok], want[~ok]) or np.isnan(got[~ok]).any(axis=1).all(), name
         print("%s: %.1f%% of components bit-identical, %.2f%% beyond 2 ulp of themselves, max |diff| %.3e" %
               (name, 100 * (d[ok] == 0).mean(), 100 * (d[ok] > 2).mean(), absd[ok].max()))
+
+
+def _exact_slab(o, d, lo, hi, tmin, tmax):
+    """Ray / box in float64 on the very fp32 values the device gets: True where the ray meets the box within [tmin, tmax]."""
+    o, d, lo, hi = (x.astype(np.float64) for x in (o, d, lo, hi))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t1, t2 = (lo - o) / d, (hi - o) / d
+    par = d == 0.0                                      # parallel to the slab: inside it or never
+    inside = (o >= lo) & (o <= hi)
+    tn = np.where(par, np.where(inside, -np.inf, np.inf), np.minimum(t1, t2))
+    tf = np.where(par, np.where(inside, np.inf, -np.inf), np.maximum(t1, t2))
+    return np.maximum(tn.max(axis=1), tmin) <= np.minimum(tf.min(axis=1), tmax.astype(np.float64))
+
+
+def test_gpu_fp16_slab_is_conservative(ctx):
+    """The default kernel's box test (pt_selftest op 19: outward fp16 planes, rotate flags in the multipliers' low mantissa
+    bits, one v_fma_mix per plane) must accept every ray that meets the box as it was before the builder's pad — triangles
+    live inside that — for origins in and far outside the scene, grazing, axis-parallel and near-degenerate directions."""
+    rng = np.random.default_rng(20261004)
+    n = 1 << 21
+    centre = np.array([100.0, -50.0, 30.0], np.float32)
+    H = np.float32(300.0)
+    e = int(np.frexp(H)[1])
+    inv_scale = np.float32(2.0 ** (e - 10))
+    coord_max = np.float32(np.abs(centre).max() + H)
+    pad_abs = np.float32(coord_max / np.float32(524288.0))
+    # inner boxes: log-uniform sizes, a quarter flat on one axis (axis-aligned triangles), a quarter touching the scene's rim
+    size = (H * np.exp(rng.uniform(np.log(1e-4), 0.0, (n, 3)))).astype(np.float32)
+    flat = rng.random(n) < 0.25
+    size[flat, rng.integers(0, 3, flat.sum())] = 0.0
+    lo0 = (centre - H + rng.random((n, 3), dtype=np.float32) * (2 * H - size)).astype(np.float32)
+    rim = rng.random(n) < 0.25
+    side = rng.integers(0, 2, (n, 3)).astype(bool)
+    lo0 = np.where(rim[:, None] & side, centre + H - size, np.where(rim[:, None], centre - H, lo0)).astype(np.float32)
+    hi0 = (lo0 + size).astype(np.float32)
+    pad = np.maximum(np.float32(1e-5) * np.maximum(np.float32(1.0), np.maximum(np.abs(lo0), np.abs(hi0))), pad_abs).astype(np.float32)
+    lo, hi = (lo0 - pad).astype(np.float32), (hi0 + pad).astype(np.float32)     # what lbvh_build.hip k_prepare hands on
+    # origins: three quarters inside the scene, the rest up to 32 scene sizes away
+    far = rng.random(n) < 0.25
+    o = (centre + (rng.random((n, 3), dtype=np.float32) * 2 - 1) * np.where(far[:, None], 64 * H, H)).astype(np.float32)
+    # directions: aimed at a point of the inner box's surface (corners, edges, faces: grazing rays), some random
+    u = rng.random((n, 3), dtype=np.float32)
+    snap = rng.integers(0, 3, (n, 3))                   # 0 -> lo plane, 1 -> hi plane, 2 -> somewhere between
+    target = np.where(snap == 0, lo0, np.where(snap == 1, hi0, lo0 + u * size)).astype(np.float32)
+    d = (target - o).astype(np.float32)
+    rnd_dir = rng.random(n) < 0.15
+    d[rnd_dir] = rng.normal(size=(int(rnd_dir.sum()), 3)).astype(np.float32)
+    d = (d / np.maximum(np.linalg.norm(d.astype(np.float64), axis=1, keepdims=True), 1e-30)).astype(np.float32)
+    # axis-parallel and near-degenerate components (incl. -0.0 and denormals)
+    for frac, val in ((0.06, 0.0), (0.02, -0.0), (0.02, 1e-30), (0.02, -1e-38), (0.02, 1e-45)):
+        m = rng.random(n) < frac
+        d[m, rng.integers(0, 3, int(m.sum()))] = np.float32(val)
+    keep = np.abs(d).max(axis=1) > 0
+    d[~keep] = np.array([0.0, 1.0, 0.0], np.float32)
+    tmax = np.where(rng.random(n) < 0.5, np.float32(1e16), (np.linalg.norm((target - o).astype(np.float64), axis=1) * rng.uniform(0.5, 1.5, n)).astype(np.float32)).astype(np.float32)
+    rec = np.concatenate([o, d, lo, hi, np.broadcast_to(centre, (n, 3)), np.full((n, 1), inv_scale, np.float32), tmax[:, None]], axis=1).astype(np.float32)
+    assert rec.shape == (n, 17)
+    out = np.zeros((n, 3), np.uint32)
+    run(ctx, 19, np.ascontiguousarray(rec), n, out)
+    accepted = out[:, 0] == 1
+    must = _exact_slab(o, d, lo0, hi0, 0.01, tmax)
+    missed = must & ~accepted
+    assert must.mean() > 0.3, "the case generator lost its hits"
+    assert not missed.any(), "box test rejected %d of %d rays that meet the unpadded box, first: %s" % (missed.sum(), must.sum(), rec[np.argmax(missed)])
+    # and it is a test, not a constant: rays that miss the box inflated by 2 % of the scene are (almost) never accepted
+    wide = _exact_slab(o, d, lo - np.float32(0.02) * H, hi + np.float32(0.02) * H, 0.01, tmax)
+    assert (~wide).mean() > 0.05
+    assert accepted[~wide].mean() < 1e-3, accepted[~wide].mean()
