@@ -19,11 +19,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=30)
     ap.add_argument("--scene", default="cornell_box.obj")
+    ap.add_argument("--variant", type=int, default=-1, help="kernel variant (pt_set_tuning; -1 = the library's choice)")
     a = ap.parse_args()
     L = _native.hip()
     orc = oracle_lib.load()
     state, obj = pt.setup(os.path.join(pt.SCENES, a.scene), width=96, height=64)
     sc = orc.scene(obj.getVerticesFloat(), obj.getIndexBuffer(), obj.getMaterialIndices(), obj.getMaterials())
+    assert L.pt_set_tuning(state.context, 0, a.variant) == 0
     rng = np.random.default_rng(2024)
     worst = 0.0
     for k in range(a.cases):
@@ -58,11 +60,16 @@ def main():
                 q = copy_params(p); q.currentFrameIdx = f
                 ref, _, rst, _ = sc.render(q, accumulation=ref, use_bvh=True, chunks=int(st.sample_chunks))
             mse = image_mse(acc, ref)
-            same = float(np.all(acc.view(np.uint32) == ref.view(np.uint32), axis=-1).mean())
+            differ = ~np.all(acc.view(np.uint32) == ref.view(np.uint32), axis=-1)
+            same = 1.0 - float(differ.mean())
             worst = max(worst, mse)
             flag = "" if mse < 1e-3 and np.isfinite(acc).all() else "   <-- FAIL"
             print("case %2d %3dx%-3d spp %2d depth %2d DL %d IS %d %s frames %d runs %2d: MSE %.2e, %.1f %% pixels bit-identical%s"
                   % (k, w, h, spp, depth, dl, isamp, "inside " if inside else "outside", frames, st.sample_chunks, mse, 100 * same, flag))
+            if mse > 1e-6:      # which pixels carry it: a path that took another branch somewhere shows as one or two pixels
+                d2 = ((acc[..., :3].astype(np.float64) - ref[..., :3]) ** 2).sum(axis=-1)
+                ys, xs = np.unravel_index(np.argsort(d2, axis=None)[::-1][:3], d2.shape)
+                print("        %d pixels differ; largest: %s" % (int(differ.sum()), "; ".join("(%d,%d) gpu %s cpu %s" % (x, y, acc[y, x, :3], ref[y, x, :3]) for y, x in zip(ys, xs) if d2[y, x] > 0)))
             sys.stdout.flush()
     print("worst MSE %.3e" % worst)
     sc.close()
