@@ -1364,6 +1364,13 @@ static const VariantDesc kVariants[] = {
     {k_render_pw<44, 16, 9, 256, 5, false, 0, 4, 2, false, 28>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) V4 T2 w5, 28 stack entries in LDS", 28},
     {k_render_pw<44, 16, 7, 256, 5, false, 0, 3, 2>, 256, 7, "pw K44 L16 fp16 min / max V3 T2 w5 (the default before the rotate amounts moved into the multipliers)"},
     {k_render_pw<44, 16, 9, 256, 5, false, 0, 6, 2>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) V6 T2 w5"},
+    {k_render_pw<44, 12, 9, 256, 5, false, 0, 5, 2>, 256, 9, "pw K44 L12 fp16 sign-rotated (low bits) V5 T2 w5"},
+    {k_render_pw<44, 20, 9, 256, 5, false, 0, 5, 2>, 256, 9, "pw K44 L20 fp16 sign-rotated (low bits) V5 T2 w5"},
+    {k_render_pw<40, 16, 9, 256, 5, false, 0, 5, 2>, 256, 9, "pw K40 L16 fp16 sign-rotated (low bits) V5 T2 w5"},
+    {k_render_pw<48, 16, 9, 256, 5, false, 0, 5, 2>, 256, 9, "pw K48 L16 fp16 sign-rotated (low bits) V5 T2 w5"},
+    {k_render_pw<44, 16, 9, 256, 5, false, 0, 5, 1>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) V5 T1 w5"},
+    {k_render_pw<36, 16, 9, 256, 5, false, 0, 5, 2>, 256, 9, "pw K36 L16 fp16 sign-rotated (low bits) V5 T2 w5"},
+    {k_render_pw<44, 24, 9, 256, 5, false, 0, 5, 2>, 256, 9, "pw K44 L24 fp16 sign-rotated (low bits) V5 T2 w5"},
     {k_render_pw<44, 16, 9, 256, 5, false, 0, 8, 2>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) V8 T2 w5"},
     {k_render_pw<44, 16, 9, 256, 5, false, 0, 5, 3>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) V5 T3 w5"},
     {k_render_pw<44, 16, 7, 256, 5, false, 0, 3, 2, false, 28>, 256, 7, "pw K44 L16 fp16 min / max V3 T2 w5, 28 stack entries in LDS", 28},
