@@ -70,3 +70,29 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".cpp", ".h", ".hip")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle_lib" not in text and "liboracle" not in text and "oracle/" not in text.replace("oracle/oracle_pt.cpp", "").replace("oracle/_ref", "").replace("oracle/Makefile", ""), f
+
+
+def test_render_kernels_keep_their_occupancy_budget(lib):
+    """Read from the built code object (no GPU): the default render kernel and its deep-tree twin are compiled for five
+    waves per SIMD — at most 96 vector registers — and the default spills none of them; the four-wave kernels stay within
+    128 without spills.  A change that pushes the BVH loop over the budget shows up here, not as a silent 10 % on the bench."""
+    import re
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_meta
+    from acgpathtracing_amd import _native
+    rows = [k for k in kernel_meta.kernel_table(_native.hip_library_path()) if "k_render_pw<" in k["name"]]
+    assert len(rows) >= 8
+    five, four = [], []
+    for k in rows:
+        args = [a.strip() for a in re.search(r"k_render_pw<([^>]*)>", k["name"]).group(1).split(",")]
+        (five if args[4] == "5" else four).append((k, args))
+    assert len(five) == 2, [k["name"] for k, _ in five]
+    for k, args in five:
+        assert k["vgpr_count"] <= 96, k
+        if args[10] == "0":                                   # the default: nothing in scratch memory
+            assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
+        else:                                                 # 28-entry LDS stack: a few spills in the shade phase are known
+            assert k["vgpr_spill_count"] <= 8, k
+    for k, args in four:
+        assert k["vgpr_count"] <= 128 and k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
