@@ -55,7 +55,7 @@ class BvhInfo(C.Structure):
                 ("scene_lo", C.c_float * 3), ("scene_hi", C.c_float * 3), ("build_ms", C.c_float),
                 ("node_bytes", C.c_uint32), ("tri_bytes", C.c_uint32),
                 ("wide_nodes", C.c_uint32), ("wide_depth", C.c_uint32), ("wide_bytes", C.c_uint32), ("wide_ms", C.c_float),
-                ("half_node_bytes", C.c_uint32), ("half_area_ratio", C.c_float)]
+                ("half_node_bytes", C.c_uint32), ("half_area_ratio", C.c_float), ("half_box_inflation", C.c_float)]
 
 
 assert C.sizeof(PathTraceParams) == 168

@@ -129,7 +129,7 @@ PT_API void pt_destroy(pt_ctx* c)
 
 static int pick_variant(const pt_ctx* c)
 {
-    const bool half_ok = c->bvh.half_area_ratio <= ptd::kHalfAreaLimit;
+    const bool half_ok = c->bvh.half_area_ratio <= ptd::kHalfAreaLimit && c->bvh.half_box_inflation <= ptd::kHalfInflationLimit;
     const bool large = c->bvh.n_tris > ptd::kLargeSceneTris;
     if (!half_ok) return large ? ptd::kVariantF32Large : ptd::kVariantF32;
     int w5_blocks = 0;      // do five workgroups of the five-wave kernel fit a CU with this tree's stack depth?
@@ -240,6 +240,7 @@ PT_API int pt_get_bvh_info(pt_ctx* c, pt_bvh_info* out)
     out->wide_ms = c->bvh.wide_ms;
     out->half_node_bytes = c->bvh.n_nodes * (uint32_t)sizeof(ptd::HNode);
     out->half_area_ratio = c->bvh.half_area_ratio;
+    out->half_box_inflation = c->bvh.half_box_inflation;
     return 0;
 }
 

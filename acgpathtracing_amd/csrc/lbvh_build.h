@@ -14,7 +14,8 @@ struct LbvhResult {
     BvhNode*   cnodes = nullptr;       // device, n_nodes (centre + half-extent boxes, 64 B)
     HNode*     hnodes = nullptr;       // device, n_nodes (fp16 boxes, 32 B)
     HSpace     hspace = {0, 0, 0, 1};
-    float      half_area_ratio = 0.0f; // sum of child-box areas after fp16 outward rounding / before: how much the coarser planes cost
+    float      half_area_ratio = 0.0f; // sum of child-box areas after fp16 outward rounding / before (what a random ray pays)
+    float      half_box_inflation = 0.0f; // mean over the child boxes of their own area after / before (what a ray through the finest geometry pays)
     QGrid      grid = {};              // world -> grid transform of qnodes
     TriRecord* tris = nullptr;         // device, n_tris, Morton order
     uint4*     wrecs = nullptr;        // device, n_wrecs x 48 B: four-wide nodes + triangles (wide_bvh.hip)

@@ -499,12 +499,13 @@ __global__ void k_centre_nodes(const BvhNode* __restrict__ nodes, uint32_t n, Bv
 
 // --- 8. fp16 copy of the nodes -------------------------------------------------------------------------
 // Planes go to the scene-centred, power-of-two scaled space of HSpace and are rounded OUTWARD to fp16 (lo down, hi up),
-// so every fp16 box contains its fp32 box.  area[0] / area[1] accumulate the child-box surface areas before / after,
-// the measure by which pt_set_scene decides whether the coarser planes are acceptable for this scene.
+// so every fp16 box contains its fp32 box.  area[0] / area[1] accumulate the child-box surface areas before / after, area[2] /
+// area[3] the number of boxes and the sum of their own after / before ratios: the measures by which pt_set_scene decides whether
+// the coarser planes are acceptable for this scene (render_megakernel.h kHalfAreaLimit, kHalfInflationLimit).
 __global__ void k_half_nodes(const BvhNode* __restrict__ nodes, uint32_t n, HSpace sp, HNode* __restrict__ hn, float* __restrict__ area)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    float before = 0.0f, after = 0.0f;
+    float before = 0.0f, after = 0.0f, boxes = 0.0f, inflation = 0.0f;
     if (i < n) {
         const BvhNode nd = nodes[i];
         const float scale = 1.0f / sp.inv_scale;
@@ -517,15 +518,24 @@ __global__ void k_half_nodes(const BvhNode* __restrict__ nodes, uint32_t n, HSpa
                          pack_planes(nd.c.x, nd.c.w, sp.cz, scale, l[5], h[5]), (uint32_t)nd.d.y);
         hn[i] = o;
         const float e0[3] = {nd.a.w - nd.a.x, nd.b.x - nd.a.y, nd.b.y - nd.a.z}, e1[3] = {nd.c.y - nd.b.z, nd.c.z - nd.b.w, nd.c.w - nd.c.x};
-        if (e0[0] >= 0.0f) before += e0[0] * e0[1] + e0[1] * e0[2] + e0[2] * e0[0];
-        if (e1[0] >= 0.0f) before += e1[0] * e1[1] + e1[1] * e1[2] + e1[2] * e1[0];
+        const float b0 = e0[0] * e0[1] + e0[1] * e0[2] + e0[2] * e0[0], b1 = e1[0] * e1[1] + e1[1] * e1[2] + e1[2] * e1[0];
+        if (e0[0] >= 0.0f) before += b0;
+        if (e1[0] >= 0.0f) before += b1;
         const float g0[3] = {(h[0] - l[0]) * sp.inv_scale, (h[1] - l[1]) * sp.inv_scale, (h[2] - l[2]) * sp.inv_scale};
         const float g1[3] = {(h[3] - l[3]) * sp.inv_scale, (h[4] - l[4]) * sp.inv_scale, (h[5] - l[5]) * sp.inv_scale};
-        if (e0[0] >= 0.0f) after += g0[0] * g0[1] + g0[1] * g0[2] + g0[2] * g0[0];
-        if (e1[0] >= 0.0f) after += g1[0] * g1[1] + g1[1] * g1[2] + g1[2] * g1[0];
+        const float a0 = g0[0] * g0[1] + g0[1] * g0[2] + g0[2] * g0[0], a1 = g1[0] * g1[1] + g1[1] * g1[2] + g1[2] * g1[0];
+        if (e0[0] >= 0.0f) after += a0;
+        if (e1[0] >= 0.0f) after += a1;
+        // per box, unweighted: a cluster of triangles below the planes' resolution inflates its own boxes many times over
+        // without moving the area sums, which the scene's large boxes dominate
+        if (e0[0] >= 0.0f && b0 > 0.0f) { boxes += 1.0f; inflation += fminf(a0 / b0, 1e4f); }
+        if (e1[0] >= 0.0f && b1 > 0.0f) { boxes += 1.0f; inflation += fminf(a1 / b1, 1e4f); }
     }
-    for (int off = 32; off > 0; off >>= 1) { before += __shfl_xor(before, off); after += __shfl_xor(after, off); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&area[0], before); atomicAdd(&area[1], after); }
+    for (int off = 32; off > 0; off >>= 1) {
+        before += __shfl_xor(before, off); after += __shfl_xor(after, off);
+        boxes += __shfl_xor(boxes, off); inflation += __shfl_xor(inflation, off);
+    }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&area[0], before); atomicAdd(&area[1], after); atomicAdd(&area[2], boxes); atomicAdd(&area[3], inflation); }
 }
 
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); return false; } } while (0)
@@ -687,15 +697,16 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
         (void)frexpf(half_ext > 0.0f && half_ext < INFINITY ? half_ext : 1.0f, &e);      // half_ext = m * 2^e, m in [0.5, 1)
         sp.inv_scale = ldexpf(1.0f, e - 10);                                             // g = w * 2^(10 - e): |g| < 1024
         float* d_area;
-        float h_area[2] = {0.0f, 0.0f};
-        HIPCK(sc.alloc(&d_area, 8));
-        HIPCK(hipMemsetAsync(d_area, 0, 8, stream));
+        float h_area[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        HIPCK(sc.alloc(&d_area, 16));
+        HIPCK(hipMemsetAsync(d_area, 0, 16, stream));
         k_half_nodes<<<(n_nodes + 255) / 256, 256, 0, stream>>>(out.nodes, n_nodes, sp, out.hnodes, d_area);
         HIPCK(hipGetLastError());
-        HIPCK(hipMemcpyAsync(h_area, d_area, 8, hipMemcpyDeviceToHost, stream));
+        HIPCK(hipMemcpyAsync(h_area, d_area, 16, hipMemcpyDeviceToHost, stream));
         HIPCK(hipStreamSynchronize(stream));
         out.hspace = sp;
         out.half_area_ratio = h_area[0] > 0.0f ? h_area[1] / h_area[0] : 1.0f;
+        out.half_box_inflation = h_area[2] > 0.0f ? h_area[3] / h_area[2] : 1.0f;
     }
     out.n_nodes = n_nodes;
     out.max_depth = (uint32_t)root_hi.w;

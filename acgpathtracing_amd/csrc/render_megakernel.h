@@ -9,14 +9,17 @@ constexpr int kRenderThreads = 256;   // 4 waves per workgroup (segment-synchron
 constexpr uint32_t kRenderFoldSlots = 128;  // fold slots per wave (render_megakernel.hip kFoldSlots)
 constexpr uint32_t kMaxTimedWaves = 16384;   // stats variants stamp start / queue-empty / end per wave behind the 8 counters
 // Variant indices of the product library (render_megakernel.hip kVariants).  pt_set_scene picks one per scene unless
-// pt_set_tuning named one.  fp16 nodes when the fp16 planes cost less than kHalfAreaLimit in summed child-box area (every
-// scene tried so far): the five-waves-per-SIMD kernel; when five workgroups' lane stacks do not fit a CU's LDS (trees deeper
-// than ~28 levels) the same kernel with the stack's tail in global memory.  fp32 nodes otherwise, with triangle rounds at 8 lanes above kLargeSceneTris.
+// pt_set_tuning named one.  fp16 nodes unless the scene has geometry finer than their planes: the mean inflation of a child
+// box by the outward fp16 rounding stays below kHalfInflationLimit (measured break-even on clusters of ever smaller triangles,
+// profiles/r02_fp16_vs_fp32_nodes.txt: fp16 nodes win by 2 ... 35 % up to 2.6, lose 6 ... 18 % from 4.0) and the area-weighted
+// ratio below kHalfAreaLimit.  Then: the five-waves-per-SIMD kernel; when five workgroups' lane stacks do not fit a CU's LDS
+// (trees deeper than ~28 levels) the same kernel with the stack's tail in global memory.  fp32 nodes otherwise, with triangle
+// rounds at 8 lanes above kLargeSceneTris.
 constexpr int kVariantSync = 0, kVariantF32 = 1, kVariantF32Stats = 2, kVariantF32Large = 3, kVariantFastMath = 4;
 constexpr int kVariantF16 = 5, kVariantF16Stats = 6, kVariantF16W5 = 7, kVariantLights = 8, kVariantF16W5Deep = 9;
 constexpr int kDefaultVariant = kVariantF16W5;
 constexpr uint32_t kLargeSceneTris = 100000;
-constexpr float kHalfAreaLimit = 1.05f;
+constexpr float kHalfAreaLimit = 1.5f, kHalfInflationLimit = 3.0f;
 
 struct FastDiv { uint32_t mul, sh1, sh2; };     // n / d = (t + ((n - t) >> sh1)) >> sh2, t = mulhi(n, mul)  (render_megakernel.hip fast_div)
 

@@ -171,7 +171,7 @@ def mtl(glass_name, metal_name):
             "newmtl %s\nKd 0.8 0.5 0.9\nPr 0.2\nPm 1.0\n" % metal_name)
 
 
-def stress_scene(path_obj, n_spheres=64, subdiv=5, seed=0x9E3779B9, mtl_name="stress_scene.mtl"):
+def stress_scene(path_obj, n_spheres=64, subdiv=5, seed=0x9E3779B9, mtl_name="stress_scene.mtl", radius_scale=1.0):
     """Seeded ~1.3 M-triangle scene inside the Cornell shell: n_spheres icospheres of
     20*4^subdiv triangles each (64 x 20480 = 1 310 720).  Positions from an LCG
     (cuda/random.h constants) with a fixed seed.  Writes path_obj and a sibling .mtl."""
@@ -192,7 +192,7 @@ def stress_scene(path_obj, n_spheres=64, subdiv=5, seed=0x9E3779B9, mtl_name="st
     sv, sf = icosphere(subdiv)
     mats = ["white", "red", "green"]
     for k in range(n_spheres):
-        r = 25.0 + 30.0 * rnd()
+        r = (25.0 + 30.0 * rnd()) * radius_scale      # radius_scale < 1: triangles below the fp16 planes' resolution (tools/make_big_scene.py)
         c = np.array([60.0 + 430.0 * rnd(), 40.0 + 440.0 * rnd(), 60.0 + 440.0 * rnd()])
         w.mesh("s%03d" % k, mats[k % 3], sv * r + c, sf)
     with open(path_obj, "w") as fh:

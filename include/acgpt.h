@@ -121,6 +121,7 @@ typedef struct pt_bvh_info {
     float    wide_ms;         /* collapse of the two-child tree, host ms      */
     uint32_t half_node_bytes; /* bytes of the fp16 node array (32 B per node)  */
     float    half_area_ratio; /* summed child-box area with fp16 planes / with fp32 planes (>= 1) */
+    float    half_box_inflation; /* mean over the child boxes of their own fp16 / fp32 area (>= 1): large where geometry is finer than the fp16 planes */
 } pt_bvh_info;
 
 /* ---- lifetime -------------------------------------------------------------
@@ -206,8 +207,8 @@ int pt_set_light_mode(pt_ctx* ctx, int mode);
 int pt_set_sample_chunks(pt_ctx* ctx, int chunks);
 
 /* Launch tuning: persistent workgroups per CU (0 = from the occupancy query) and the render
- * kernel variant: -1 = chosen per scene (the default: fp16 nodes where their coarser planes cost < 5 % of
- * summed child-box area, fp32 nodes otherwise), 0 = segment-synchronous, n >= 1 = persistent traversal
+ * kernel variant: -1 = chosen per scene (the default: fp16 nodes unless the scene has geometry finer than their planes —
+ * pt_bvh_info.half_box_inflation above 3 —, fp32 nodes then), 0 = segment-synchronous, n >= 1 = persistent traversal
  * with deferred shading, see csrc/render_megakernel.hip.  Every variant produces the same image bits.   */
 int pt_set_tuning(pt_ctx* ctx, int blocks_per_cu, int variant);
 /* Human-readable description of a kernel variant, NULL past the last one.  Names starting with "DIAG"

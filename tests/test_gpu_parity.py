@@ -479,6 +479,33 @@ def test_large_scene_properties(gpu_state_factory, oracle, tmp_path):
     assert L.pt_set_sample_chunks(state.context, 1) == 0
 
 
+def test_node_format_follows_the_geometry(gpu_state_factory, oracle, tmp_path):
+    """pt_set_scene's choice between fp16 and fp32 nodes: spheres of ordinary size keep the fp16 planes' inflation of a box small
+    and get the fp16 kernel; the same spheres shrunk to a fiftieth are finer than the planes (mean box inflation > 3: whole
+    subtrees collapse onto the same fp16 planes) and get the fp32 kernel.  Both images agree with the oracle either way."""
+    import sys
+    sys.path.insert(0, pt.SCENES)
+    import make_scenes
+    L = _native.hip()
+    for scale, want in ((1.0, "fp16"), (0.02, "fp32")):
+        path = str(tmp_path / ("spheres_%g.obj" % scale))
+        make_scenes.stress_scene(path, n_spheres=8, subdiv=4, radius_scale=scale)
+        state, obj = gpu_state_factory(path, sample_chunks=1, width=64, height=48)
+        info = pt.getBvhInfo(state)
+        assert info.n_tris == 8 * 5120 + 12
+        assert 1.0 <= info.half_area_ratio < 1.5
+        assert (info.half_box_inflation <= 3.0) == (want == "fp16"), (scale, info.half_box_inflation)
+        p = make_params(64, 48, 8, 5, True, True)
+        acc, fb, st = _gpu_render(state, p)
+        name = L.pt_variant_name(int(st[0].variant)).decode()
+        print("radius x %g: area ratio %.4f, mean box inflation %.3f -> %s" % (scale, info.half_area_ratio, info.half_box_inflation, name))
+        assert want in name, name
+        sc = oracle.scene(obj.getVerticesFloat(), obj.getIndexBuffer(), obj.getMaterialIndices(), obj.getMaterials())
+        ref, _, _, _ = sc.render(copy_params(p), use_bvh=True)
+        assert image_mse(acc, ref) < MSE_TOL
+        sc.close()
+
+
 def test_headless_app_matches_the_python_path(full, tmp_path):
     """acgpt_main (the C++ mirror of PathTracerMain.cpp) and the Python mirror drive the same library: the
     same frames, the same bytes — including the key replay (toggle importance sampling, reset)."""
