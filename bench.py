@@ -175,7 +175,11 @@ def roofline_block(a, info, world, fuse, kernel_ms, rays_per_launch, steps_per_l
     my_pixels = a.width * a.height / world
     algo_bytes = rays_per_launch * b_ray + 36.0 * my_pixels * steps_per_launch
     algo_flops = rays_per_launch * f_ray
-    scene_bytes = int(info.node_bytes) + int(info.tri_bytes)
+    half = "fp16" in variant_name                    # the node array the kernel that ran walks: 32-byte fp16 or 64-byte fp32 nodes
+    scene_bytes = int(info.half_node_bytes if half else info.node_bytes) + int(info.tri_bytes)
+    kernel_b_ray = (32 if half else 64) * levels + 48   # what this kernel's formats move per ray of the SURVEY model: one node per level + one triangle record
+    kernel_bytes = rays_per_launch * kernel_b_ray + 36.0 * my_pixels * steps_per_launch
+    kernel_gbs = kernel_bytes / ksec / 1e9 if ksec > 0 else 0.0
     resident = "L2" if scene_bytes <= L2_BYTES else ("Infinity Cache" if scene_bytes <= MALL_BYTES else "HBM")
     model_gbs = algo_bytes / ksec / 1e9 if ksec > 0 else 0.0
     valu_tf = algo_flops / ksec / 1e12 if ksec > 0 else 0.0
@@ -204,7 +208,10 @@ def roofline_block(a, info, world, fuse, kernel_ms, rays_per_launch, steps_per_l
                        "note": "SURVEY.md 8d byte model; for a cache-resident scene these bytes are served by L1/L2/Infinity Cache, so this is not an HBM fraction"},
          "valu_model": {"algorithmic_flops_per_ray": f_ray, "TFLOPs": valu_tf, "frac_of_fp32_vector_peak": valu_tf / FP32_PEAK_TFLOPS}}
     if resident == "HBM":
-        r.update({"bound": "hbm", "achieved": model_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": model_gbs / HBM_PEAK_GBS})
+        # priced with the bytes of the node format that ran (an fp16 node is half the SURVEY model's 64 B), so that a compact
+        # format does not read as bandwidth
+        r.update({"bound": "hbm", "achieved": kernel_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kernel_gbs / HBM_PEAK_GBS,
+                  "algorithmic_bytes_per_ray_this_kernel": kernel_b_ray})
     else:
         r.update({"bound": "valu", "achieved": valu_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": valu_tf / FP32_PEAK_TFLOPS})
     return r
