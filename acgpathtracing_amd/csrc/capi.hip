@@ -314,7 +314,7 @@ PT_API int pt_set_stream(pt_ctx* c, void* s)
 static ptd::DeviceScene device_scene(pt_ctx* c)
 {
     ptd::DeviceScene sc;
-    sc.nodes = c->bvh.nodes; sc.qnodes = c->bvh.qnodes; sc.cnodes = c->bvh.cnodes; sc.hnodes = c->bvh.hnodes; sc.hspace = c->bvh.hspace; sc.grid = c->bvh.grid; sc.tris = c->bvh.tris; sc.wrecs = c->bvh.wrecs; sc.mats = c->d_mats;
+    sc.nodes = c->bvh.nodes; sc.qnodes = c->bvh.qnodes; sc.cnodes = c->bvh.cnodes; sc.hnodes = c->bvh.hnodes; sc.hspace = c->bvh.hspace; sc.grid = c->bvh.grid; sc.tris = c->bvh.tris; sc.shade = c->bvh.shade; sc.wrecs = c->bvh.wrecs; sc.mats = c->d_mats;
     sc.n_tris = c->bvh.n_tris; sc.n_mats = c->n_mats;
     sc.lights = c->d_lights; sc.n_lights = c->n_lights; sc.light_area = c->light_area;
     return sc;

@@ -18,6 +18,7 @@ struct LbvhResult {
     float      half_box_inflation = 0.0f; // mean over the child boxes of their own area after / before (what a ray through the finest geometry pays)
     QGrid      grid = {};              // world -> grid transform of qnodes
     TriRecord* tris = nullptr;         // device, n_tris, Morton order
+    float4*    shade = nullptr;        // device, n_tris, same order: geometric normal + material id (pt_device.h DeviceScene::shade)
     uint4*     wrecs = nullptr;        // device, n_wrecs x 48 B: four-wide nodes + triangles (wide_bvh.hip)
     uint32_t   n_wrecs = 0, n_wnodes = 0, wide_depth = 0;
     float      wide_ms = 0.0f;         // host collapse + upload

@@ -282,10 +282,16 @@ __device__ __forceinline__ QNode quantise_node(const QGrid g, const float4 l0, c
 
 // --- 5. sorted leaves + bottom-up refit ------------------------------------------------
 __global__ void k_gather_leaves(const uint32_t* __restrict__ vals_sorted, uint32_t n, const TriRecord* __restrict__ tri_unsorted,
-                                TriRecord* __restrict__ tris)
+                                TriRecord* __restrict__ tris, float4* __restrict__ shade)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) tris[i] = tri_unsorted[vals_sorted[i]];
+    if (i >= n) return;
+    const TriRecord r = tri_unsorted[vals_sorted[i]];
+    tris[i] = r;
+    // what closest-hit shading needs of the triangle: N_0 = normalize(cross(v1 - v0, v2 - v0)) (pathTracerPrograms.cu:890; the
+    // same device functions the shade phase would call, so the same bits) and the material id
+    const f3 n0 = normalize(cross(mk(r.r0.w, r.r1.x, r.r1.y), mk(r.r1.z, r.r1.w, r.r2.x)));
+    shade[i] = make_float4(n0.x, n0.y, n0.z, r.r2.z);
 }
 
 __global__ void k_refit(int n, const uint32_t* __restrict__ vals_sorted, const float4* __restrict__ tri_lo, const float4* __restrict__ tri_hi,
@@ -567,6 +573,7 @@ void free_lbvh(LbvhResult& r)
     if (r.cnodes) (void)hipFree(r.cnodes);
     if (r.hnodes) (void)hipFree(r.hnodes);
     if (r.tris) (void)hipFree(r.tris);
+    if (r.shade) (void)hipFree(r.shade);
     if (r.wrecs) (void)hipFree(r.wrecs);
     if (r.keys_sorted) (void)hipFree(r.keys_sorted);
     if (r.vals_sorted) (void)hipFree(r.vals_sorted);
@@ -613,6 +620,7 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
     HIPCK(hipMalloc((void**)&out.cnodes, (size_t)n_nodes * sizeof(BvhNode)));
     HIPCK(hipMalloc((void**)&out.hnodes, (size_t)n_nodes * sizeof(HNode)));
     HIPCK(hipMalloc((void**)&out.tris, (size_t)n * sizeof(TriRecord)));
+    HIPCK(hipMalloc((void**)&out.shade, (size_t)n * sizeof(float4)));
     HIPCK(hipMalloc((void**)&out.keys_sorted, (size_t)n * 4));
     HIPCK(hipMalloc((void**)&out.vals_sorted, (size_t)n * 4));
 
@@ -637,7 +645,7 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
     }
     HIPCK(hipMemcpyAsync(out.keys_sorted, d_keys[cur], (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
     HIPCK(hipMemcpyAsync(out.vals_sorted, d_vals[cur], (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
-    k_gather_leaves<<<blocks, 256, 0, stream>>>(d_vals[cur], n, d_unsorted, out.tris);
+    k_gather_leaves<<<blocks, 256, 0, stream>>>(d_vals[cur], n, d_unsorted, out.tris, out.shade);
     if (n > 1 && mode == 1) {
         // PLOC over the sorted order; the cluster arrays ping-pong, flags/positions reuse scratch
         Cluster* d_c[2]; uint32_t *d_nn, *d_keep, *d_made;

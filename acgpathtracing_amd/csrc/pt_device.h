@@ -8,6 +8,9 @@
 //            original triangle index, material id.  Edges are the single fp32 subtraction
 //            the reference's closest-hit performs (pathTracerPrograms.cu:890), so shading
 //            needs no second fetch through the index buffer.
+//   shade  : float4[n_tris], same order: the triangle's geometric normal — normalize(cross(e1, e2)), the very operations of
+//            pathTracerPrograms.cu:890, done once by the builder — and its material id: one 16-byte fetch per shaded hit
+//            instead of the record's three, and no normalisation (a sqrt and a division) in the shade phase.
 //   mats   : pt_material[n_mats] (40 B, HitGroupData's payload, pathTracer.h:118-127).
 // Compile with -ffp-contract=off: the only fused multiply-adds are the explicit ones in
 // tri_test(), which must match oracle/oracle_pt.cpp bit for bit.
@@ -73,6 +76,7 @@ struct DeviceScene {
     HSpace             hspace;
     QGrid              grid;
     const TriRecord*   tris;
+    const float4*      shade;     // per leaf slot: geometric normal normalize(cross(e1, e2)) (:890) and material id — what closest-hit shading reads
     const uint4*       wrecs;     // four-wide tree: 48-byte records, wide nodes and triangles in one array (wide_bvh.hip)
     const pt_material* mats;
     uint32_t n_tris;

@@ -161,18 +161,27 @@ struct Pending {
 // TRIG_DIAG (kernel variant 10, opt-in): the cosine-weighted sampler with v_sin_f32 / v_cos_f32 and sqrt(1 - z1) for
 // sin(acos(sqrt(z1))) — the kind of arithmetic the reference's own build uses (nvcc --use_fast_math, CMakeLists.txt:267).
 // Different low bits than the default path, same image within the parity tolerance (test_fast_math_variant).
-template <bool TRIG_DIAG = false, typename Late>
+// FROM_RECORD: normal and material from the triangle record itself (`slot` indexes sc.tris; the four-wide experiment, whose
+// slots are positions in its own record array) instead of the builder's shading record
+template <bool TRIG_DIAG = false, bool FROM_RECORD = false, typename Late>
 __device__ __forceinline__ bool shade_hit(const DeviceScene& sc, Late late, const f3& org, const f3& dir,
                                           float t_hit, int slot, int depth, uint32_t& pseed, f3& att, f3& emission,
                                           Pending& pd, f3& P, f3& L, float& Ldist)
 {
-    const TriRecord* tp = sc.tris + slot;
-    const float4 r0 = tp->r0, r1 = tp->r1, r2 = tp->r2;
-    const pt_material* mp = sc.mats + __float_as_uint(r2.z);
+    float4 sr;                                                                   // :890 N_0 = normalize(cross(v1 - v0, v2 - v0)), material id
+    if (FROM_RECORD) {
+        const TriRecord* tp = sc.tris + slot;
+        const float4 r0 = tp->r0, r1 = tp->r1, r2 = tp->r2;
+        const f3 n0 = normalize(cross(mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x)));
+        sr = make_float4(n0.x, n0.y, n0.z, r2.z);
+    } else {
+        sr = sc.shade[slot];                                                     // computed once by the builder (k_gather_leaves)
+    }
+    const pt_material* mp = sc.mats + __float_as_uint(sr.w);
     const f3 Kd = mk(mp->diffuse), Ke = mk(mp->emission);
     const float IOR = mp->ior;
     const int bsdf = mp->bsdfType;
-    const f3 N0 = normalize(cross(mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x)));   // :890
+    const f3 N0 = mk(sr.x, sr.y, sr.z);
     const f3 N = faceforward(N0, -dir, N0);
     P = org + t_hit * dir;                                                       // :894
     emission = depth == 0 ? Ke : mk(0.0f);                                       // :898-901
@@ -245,12 +254,11 @@ __device__ __forceinline__ bool shade_hit_lights(const DeviceScene& sc, Late lat
                                                  float t_hit, int slot, int depth, uint32_t& pseed, f3& att, float& prev_pdf,
                                                  Pending& pd, f3& P, f3& L, float& Ldist)
 {
-    const TriRecord* tp = sc.tris + slot;
-    const float4 r0 = tp->r0, r1 = tp->r1, r2 = tp->r2;
-    const pt_material* mp = sc.mats + __float_as_uint(r2.z);
+    const float4 sr = sc.shade[slot];
+    const pt_material* mp = sc.mats + __float_as_uint(sr.w);
     const f3 Kd = mk(mp->diffuse), Ke = mk(mp->emission);
     const int bsdf = mp->bsdfType;
-    const f3 N0 = normalize(cross(mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x)));
+    const f3 N0 = mk(sr.x, sr.y, sr.z);
     const f3 N = faceforward(N0, -dir, N0);
     P = org + t_hit * dir;
     const auto& La = late();

@@ -568,7 +568,7 @@ k_render_pw(const RenderArgsBox B)
                 f3 P, L; float Ldist;
                 if (best_slot >= 0) {
                     if (LIGHTS) want_shadow = shade_hit_lights(sc, late, ro, rd, best_t, best_slot, depth, pseed, att, prev_pdf, pd, P, L, Ldist);
-                    else want_shadow = shade_hit<DIAG == 3>(sc, late, ro, rd, best_t, best_slot, depth, pseed, att, emission, pd, P, L, Ldist);
+                    else want_shadow = shade_hit<DIAG == 3, NODE_FMT == 3>(sc, late, ro, rd, best_t, best_slot, depth, pseed, att, emission, pd, P, L, Ldist);
                 } else {                                              // __miss__ms :833-847
                     pd.radiance = mk(0.0f); pd.weight = 0.0f; pd.done = true;
                 }
