@@ -323,7 +323,8 @@ def main():
                               vname.decode() if vname else "?")
         miss = primary_miss_fraction(p, info)
         out = {
-            "metric": "Mray/s at 1080p, %d spp, %d bounces (radiance + shadow rays per second)" % (a.spp * a.steps, a.max_depth),
+            "metric": "Mray/s at %s, %d spp, %d bounces (radiance + shadow rays per second)"
+                      % ("1080p" if (a.width, a.height) == (WIDTH, HEIGHT) else "%dx%d" % (a.width, a.height), a.spp * a.steps, a.max_depth),
             "value": all_rays / elapsed / 1e6,
             "unit": "Mray/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
