@@ -37,14 +37,30 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+KERNEL_SOURCES = ["render_megakernel.hip", "render_megakernel.h", "pt_device.h", "pt_shading.h"]
+
+
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over the sources of the render kernels: compiled into the library
+    (pt_kernel_source_hash) and recorded by tools/summarize_prof.py, so that bench.py quotes a committed profile only
+    for the kernel code it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(CSRC, name), "rb") as fh:
+            h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def build_hip(force=False, verbose=False, experiments=False):
     """experiments=True builds libacgpt_hip_exp.so: the same library plus every kernel variant that was measured and
     not adopted (-DACGPT_EXPERIMENTS; tools/sweep_variants.py loads it via ACGPT_EXPERIMENTS=1).  Never the product."""
     out = os.path.join(PKG, "libacgpt_hip_exp.so" if experiments else "libacgpt_hip.so")
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in HIP_HEADERS] + [os.path.join(ROOT, "include", "acgpt.h")]
+    deps = srcs + [os.path.join(CSRC, h) for h in HIP_HEADERS] + [os.path.join(ROOT, "include", "acgpt.h"), os.path.join(ROOT, "include", "acgpt_test.h")]
     if force or _stale(out, deps):
-        cmd = [_hipcc()] + HIP_FLAGS + (["-DACGPT_EXPERIMENTS"] if experiments else []) + ["-o", out] + srcs
+        cmd = [_hipcc()] + HIP_FLAGS + (["-DACGPT_EXPERIMENTS"] if experiments else []) + \
+              ['-DACGPT_KERNEL_SRC_HASH="%s"' % kernel_source_hash(), "-o", out] + srcs + ["-ldl", "-pthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT if not verbose else None)

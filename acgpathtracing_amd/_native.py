@@ -47,7 +47,7 @@ class Stats(C.Structure):
     _fields_ = [("radiance_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("paths", C.c_uint64),
                 ("kernel_ms", C.c_float), ("launch_ms", C.c_float), ("pixels", C.c_uint32), ("grid_blocks", C.c_uint32), ("sample_chunks", C.c_uint32), ("variant", C.c_uint32),
                 ("trav_wave_steps", C.c_uint64), ("trav_lane_steps", C.c_uint64),
-                ("shade_wave_rounds", C.c_uint64), ("shade_lane_rounds", C.c_uint64)]
+                ("shade_wave_rounds", C.c_uint64), ("shade_lane_rounds", C.c_uint64), ("culled_rays", C.c_uint64)]
 
 
 class BvhInfo(C.Structure):
@@ -61,15 +61,20 @@ class BvhInfo(C.Structure):
 assert C.sizeof(PathTraceParams) == 168
 assert C.sizeof(Material) == 40
 assert C.sizeof(AreaLight) == 60
+assert C.sizeof(Stats) == 88 and C.sizeof(BvhInfo) == 80          # ABI version 2 (include/acgpt.h)
+ABI_VERSION = 2
 
-# every symbol include/acgpt.h declares
+# every symbol include/acgpt.h declares (the drop-in boundary) ...
 ABI_SYMBOLS = [
-    "pt_create", "pt_destroy", "pt_last_error", "pt_set_scene", "pt_set_build_mode", "pt_scene_handle", "pt_get_bvh_info",
-    "pt_launch", "pt_launch_frames", "pt_resolve_framebuffer", "pt_set_partition", "pt_set_sample_chunks", "pt_set_light_mode", "pt_set_scratch_limit", "pt_set_tuning", "pt_variant_name", "pt_set_stream", "pt_get_stats",
-    "pt_trace_closest", "pt_trace_any", "pt_bench_traversal", "pt_selftest", "pt_debug_wave_times", "pt_debug_queue_progress", "pt_read_morton",
+    "pt_create", "pt_create_multi", "pt_device_count", "pt_destroy", "pt_last_error", "pt_set_scene", "pt_set_build_mode", "pt_scene_handle", "pt_get_bvh_info",
+    "pt_launch", "pt_launch_frames", "pt_resolve_framebuffer", "pt_set_partition", "pt_set_sample_chunks", "pt_set_light_mode", "pt_set_scratch_limit", "pt_set_tuning",
+    "pt_variant_name", "pt_variant_kernel", "pt_kernel_source_hash", "pt_set_stream", "pt_get_stats",
+    "pt_trace_closest", "pt_trace_any",
     "pt_device_malloc", "pt_device_free", "pt_device_memset", "pt_copy_to_host", "pt_copy_to_device",
     "pt_host_malloc_mapped", "pt_host_free_mapped", "pt_abi_version",
 ]
+# ... and include/acgpt_test.h (test hooks and diagnostics; same library)
+TEST_SYMBOLS = ["pt_bench_traversal", "pt_selftest", "pt_debug_wave_times", "pt_debug_queue_progress", "pt_read_morton"]
 
 _hip = None
 _host = None
@@ -100,6 +105,10 @@ def hip():
     L = C.CDLL(path)
     vp, sz, u32p, f32p = C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_float)
     L.pt_create.argtypes = [C.POINTER(vp), C.c_int]; L.pt_create.restype = C.c_int
+    L.pt_create_multi.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]; L.pt_create_multi.restype = C.c_int
+    L.pt_device_count.argtypes = [vp]; L.pt_device_count.restype = C.c_int
+    L.pt_variant_kernel.argtypes = [C.c_int]; L.pt_variant_kernel.restype = C.c_char_p
+    L.pt_kernel_source_hash.argtypes = []; L.pt_kernel_source_hash.restype = C.c_char_p
     L.pt_destroy.argtypes = [vp]; L.pt_destroy.restype = None
     L.pt_last_error.argtypes = [vp]; L.pt_last_error.restype = C.c_char_p
     L.pt_set_scene.argtypes = [vp, vp, sz, vp, sz, vp, vp, sz]; L.pt_set_scene.restype = C.c_int
@@ -132,6 +141,8 @@ def hip():
     L.pt_host_malloc_mapped.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), sz]; L.pt_host_malloc_mapped.restype = C.c_int
     L.pt_host_free_mapped.argtypes = [vp, vp]; L.pt_host_free_mapped.restype = C.c_int
     L.pt_abi_version.argtypes = []; L.pt_abi_version.restype = C.c_uint32
+    if L.pt_abi_version() != ABI_VERSION:
+        raise RuntimeError("libacgpt_hip.so has ABI version %d, this binding expects %d: rebuild (__graft_entry__.build())" % (L.pt_abi_version(), ABI_VERSION))
     _hip = L
     return L
 

@@ -2,15 +2,20 @@
 // Each export names the reference function it stands in for (see acgpt.h).  There is no
 // CPU path in this library: every entry point fails if no HIP device is usable.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types only: librccl is loaded with dlopen by pt_create_multi, a single-GPU caller never touches it
+#include <dlfcn.h>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/acgpt.h"
+#include "../../include/acgpt_test.h"
 #include "lbvh_build.h"
 #include "pt_device.h"
 #include "render_megakernel.h"
@@ -21,6 +26,9 @@
 static_assert(sizeof(pt_params) == 168, "pt_params must mirror PathTraceParams (168 bytes)");
 static_assert(sizeof(pt_material) == 40, "pt_material must mirror Material (40 bytes)");
 static_assert(sizeof(pt_area_light) == 60, "pt_area_light must mirror AreaLight (60 bytes)");
+static_assert(sizeof(pt_stats) == 88 && sizeof(pt_bvh_info) == 80, "ABI version 2: a change of these layouts bumps pt_abi_version");
+
+struct pt_multi;
 
 struct pt_ctx {
     int device = 0;
@@ -49,6 +57,9 @@ struct pt_ctx {
     float* d_wave_scratch = nullptr; size_t wave_scratch_bytes = 0;    // fold slots of every wave of the grid
     uint32_t* d_stack_ovf = nullptr; size_t stack_ovf_bytes = 0;       // stack entries beyond a kernel's LDS cap
     size_t scratch_limit = (size_t)1 << 30;                          // a frame batch is cut into launches whose frame sums fit
+    // division constants of the tile order, valid for (div_width, div_world_n): built and verified once per image width
+    uint32_t div_width = 0; int div_world_n = 0; ptd::FastDiv div_cols = {0, 0, 0}, div_world = {0, 0, 0};
+    pt_multi* multi = nullptr;                // pt_create_multi: this context is rank 0 of a group (below)
     pt_stats stats;
     uint64_t scene_serial = 0;
     std::string err;
@@ -66,7 +77,60 @@ static int fail(pt_ctx* c, const std::string& m)
 }
 #define CK(c, x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail((c), std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
-PT_API uint32_t pt_abi_version(void) { return 1u; }
+// ---- ROCTx ranges (tracing): scene build, launch, finalize, reduce show up labelled in a
+// `rocprofv3 --marker-trace` of any caller.  The marker library is looked up once at run time; without it the ranges are no-ops.
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        void* h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (!push || !pop) { push = nullptr; pop = nullptr; }
+    }
+};
+static Roctx& roctx() { static Roctx r; return r; }
+struct Range {
+    bool on;
+    explicit Range(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+    ~Range() { if (on) roctx().pop(); }
+};
+}  // namespace
+
+// ---- multi-GPU group (pt_create_multi): rank 0 is the context the caller holds; it owns the others -----------------
+// One context, stream and host thread per device; the tile partition of sutil/WorkDistribution.h:50-81 per rank; each rank
+// accumulates its own pixels in a private full-size float4 buffer that is zero elsewhere; ONE ncclReduce(SUM) per launch
+// brings them into the caller's accumulation buffer on rank 0 (every pixel has exactly one non-zero term, so the sum is
+// that term bit for bit) and rank 0 applies make_color.  Replaces the dormant multi-GPU branch of the reference
+// (sutil/WorkDistribution.h, sutil/CUDAOutputBuffer.h CUDA_P2P).
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+struct pt_multi {
+    std::vector<pt_ctx*> ranks;          // ranks[0] = the context the caller holds
+    std::vector<float4*> accum;          // private accumulation buffer of each rank (its own pixels, zero elsewhere)
+    size_t accum_pixels = 0;
+    bool rehearsal = false;              // all ranks on ONE device (one-GPU box): a sum kernel stands in for RCCL
+    RcclApi rccl;
+    std::vector<ncclComm_t> comms;
+    const void* cont_accum = nullptr;    // the caller's buffer and the frame index a straight continuation would pass next
+    uint32_t cont_frame = 0, cont_w = 0, cont_h = 0;
+    float reduce_ms = 0.0f;
+    pt_stats group_stats;
+};
+
+PT_API uint32_t pt_abi_version(void) { return 2u; }
 
 PT_API const char* pt_last_error(pt_ctx* ctx)
 {
@@ -75,9 +139,8 @@ PT_API const char* pt_last_error(pt_ctx* ctx)
     return g_err.c_str();
 }
 
-PT_API int pt_create(pt_ctx** out, int device_id)
+static int create_one(pt_ctx** out, int device_id)
 {
-    if (!out) return fail(nullptr, "pt_create: out is null");
     *out = nullptr;
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -92,12 +155,97 @@ PT_API int pt_create(pt_ctx** out, int device_id)
     memset(&c->stats, 0, sizeof(c->stats));
     if (hipStreamCreate(&c->own_stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipMalloc((void**)&c->d_queue, 8 * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void**)&c->d_counters, (8 + 3 * (size_t)ptd::kMaxTimedWaves + 2056) * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc((void**)&c->d_counters, (size_t)ptd::kCounterWords * sizeof(unsigned long long)) != hipSuccess) {
         delete c;
         return fail(nullptr, "pt_create: device resource allocation failed");
     }
     c->stream = c->own_stream;
     *out = c;
+    return 0;
+}
+
+PT_API int pt_create(pt_ctx** out, int device_id)
+{
+    if (!out) return fail(nullptr, "pt_create: out is null");
+    return create_one(out, device_id);
+}
+
+static void destroy_one(pt_ctx* c);
+
+static bool load_rccl(RcclApi& r, std::string& err)
+{
+    r.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!r.lib) r.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!r.lib) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
+    r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.lib, "ncclCommInitAll");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+    r.Reduce = (decltype(r.Reduce))dlsym(r.lib, "ncclReduce");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+    if (!r.CommInitAll || !r.CommDestroy || !r.Reduce || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) { err = "librccl lacks a collective entry point"; return false; }
+    return true;
+}
+
+PT_API int pt_create_multi(pt_ctx** out, const int* device_ids, int n_devices)
+{
+    if (!out) return fail(nullptr, "pt_create_multi: out is null");
+    *out = nullptr;
+    if (!device_ids || n_devices < 1 || n_devices > 16) return fail(nullptr, "pt_create_multi: need 1 to 16 device ids");
+    bool dup = false;
+    for (int i = 0; i < n_devices; i++) for (int j = 0; j < i; j++) dup = dup || device_ids[i] == device_ids[j];
+    const char* reh = getenv("ACGPT_REHEARSE_SAME_GPU");
+    if (dup && !(reh && reh[0] == '1'))
+        return fail(nullptr, "pt_create_multi: a device id appears twice (allowed only as a rehearsal on a one-GPU box: ACGPT_REHEARSE_SAME_GPU=1)");
+    pt_multi* m = new pt_multi();
+    m->rehearsal = dup;
+    for (int i = 0; i < n_devices; i++) {
+        pt_ctx* c = nullptr;
+        if (create_one(&c, device_ids[i]) != 0) {
+            for (pt_ctx* k : m->ranks) destroy_one(k);
+            delete m;
+            return 1;
+        }
+        c->rank = i; c->world = n_devices;
+        m->ranks.push_back(c);
+    }
+    m->accum.assign((size_t)n_devices, nullptr);
+    if (!m->rehearsal) {
+        std::string err;
+        bool ok = load_rccl(m->rccl, err);
+        if (ok) {
+            m->comms.assign((size_t)n_devices, nullptr);
+            const ncclResult_t r = m->rccl.CommInitAll(m->comms.data(), n_devices, device_ids);
+            if (r != ncclSuccess) { ok = false; err = std::string("ncclCommInitAll: ") + m->rccl.GetErrorString(r); m->comms.clear(); }
+        }
+        if (!ok) {
+            for (pt_ctx* k : m->ranks) destroy_one(k);
+            if (m->rccl.lib) dlclose(m->rccl.lib);
+            delete m;
+            return fail(nullptr, "pt_create_multi: " + err);
+        }
+    }
+    m->ranks[0]->multi = m;
+    *out = m->ranks[0];
+    return 0;
+}
+
+PT_API int pt_device_count(pt_ctx* c) { return !c ? 0 : (c->multi ? (int)c->multi->ranks.size() : 1); }
+
+// f(rank context, rank index) on every rank of a group, each on its own host thread (rank 0 on the caller's); the first
+// failure's message becomes the group's
+template <typename F>
+static int on_every_rank(pt_ctx* c, F f)
+{
+    pt_multi* m = c->multi;
+    const size_t n = m->ranks.size();
+    std::vector<int> rc(n, 0);
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < n; i++) th.emplace_back([&, i]() { rc[i] = f(m->ranks[i], (int)i); });
+    rc[0] = f(m->ranks[0], 0);
+    for (auto& t : th) t.join();
+    for (size_t i = 0; i < n; i++)
+        if (rc[i] != 0) return fail(c, "rank " + std::to_string(i) + " (device " + std::to_string(m->ranks[i]->device) + "): " + m->ranks[i]->err);
     return 0;
 }
 
@@ -113,6 +261,20 @@ static void free_scene(pt_ctx* c)
 PT_API void pt_destroy(pt_ctx* c)
 {
     if (!c) return;
+    if (pt_multi* m = c->multi) {
+        c->multi = nullptr;
+        for (size_t i = 0; i < m->ranks.size(); i++) { (void)hipSetDevice(m->ranks[i]->device); (void)hipStreamSynchronize(m->ranks[i]->stream); }
+        for (ncclComm_t k : m->comms) if (k) (void)m->rccl.CommDestroy(k);
+        for (size_t i = 0; i < m->ranks.size(); i++) if (m->accum[i]) { (void)hipSetDevice(m->ranks[i]->device); (void)hipFree(m->accum[i]); }
+        for (size_t i = 1; i < m->ranks.size(); i++) destroy_one(m->ranks[i]);
+        // librccl stays loaded: unloading a library that owns threads and device state at this point buys nothing
+        delete m;
+    }
+    destroy_one(c);
+}
+
+static void destroy_one(pt_ctx* c)
+{
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_scene(c);
@@ -162,7 +324,7 @@ static int ensure_wide(pt_ctx* c)
     return size_stack(c);
 }
 
-PT_API int pt_set_scene(pt_ctx* c, const float* verts_xyzw, size_t n_verts, const uint32_t* idx, size_t n_tris,
+static int set_scene_one(pt_ctx* c, const float* verts_xyzw, size_t n_verts, const uint32_t* idx, size_t n_tris,
                         const uint32_t* mat_ids, const pt_material* mats, size_t n_mats)
 {
     if (!c) return fail(nullptr, "pt_set_scene: null context");
@@ -177,6 +339,7 @@ PT_API int pt_set_scene(pt_ctx* c, const float* verts_xyzw, size_t n_verts, cons
         if (mats[i].bsdfType < 0 || mats[i].bsdfType > 2) return fail(c, "pt_set_scene: unknown bsdfType");
     CK(c, hipSetDevice(c->device));
     CK(c, hipStreamSynchronize(c->stream));
+    Range range("acgpt: scene upload + BVH build");
     free_scene(c);
     std::string err;
     if (!ptd::build_lbvh(verts_xyzw, n_verts, idx, n_tris, mat_ids, c->build_mode, c->stream, c->bvh, err)) return fail(c, "pt_set_scene: " + err);
@@ -247,12 +410,13 @@ PT_API int pt_get_bvh_info(pt_ctx* c, pt_bvh_info* out)
 PT_API int pt_set_partition(pt_ctx* c, int rank, int world)
 {
     if (!c) return fail(nullptr, "pt_set_partition: null context");
+    if (c->multi) return fail(c, "pt_set_partition: a pt_create_multi group partitions the image itself");
     if (world < 1 || rank < 0 || rank >= world) return fail(c, "pt_set_partition: need 0 <= rank < world");
     c->rank = rank; c->world = world;
     return 0;
 }
 
-PT_API int pt_set_scratch_limit(pt_ctx* c, size_t bytes)
+static int set_scratch_limit_one(pt_ctx* c, size_t bytes)
 {
     if (!c) return fail(nullptr, "pt_set_scratch_limit: null context");
     if (bytes < ((size_t)1 << 20)) return fail(c, "pt_set_scratch_limit: at least 1 MiB");
@@ -260,7 +424,7 @@ PT_API int pt_set_scratch_limit(pt_ctx* c, size_t bytes)
     return 0;
 }
 
-PT_API int pt_set_light_mode(pt_ctx* c, int mode)
+static int set_light_mode_one(pt_ctx* c, int mode)
 {
     if (!c) return fail(nullptr, "pt_set_light_mode: null context");
     if (mode != 0 && mode != 1) return fail(c, "pt_set_light_mode: 0 = the reference's estimator (hard-coded rectangle, PathTracerMain.cpp:154-158), 1 = scene lights + MIS");
@@ -268,7 +432,7 @@ PT_API int pt_set_light_mode(pt_ctx* c, int mode)
     return 0;
 }
 
-PT_API int pt_set_sample_chunks(pt_ctx* c, int chunks)
+static int set_sample_chunks_one(pt_ctx* c, int chunks)
 {
     if (!c) return fail(nullptr, "pt_set_sample_chunks: null context");
     if (chunks != 0 && chunks != 1 && chunks != 2 && chunks != 4 && chunks != 8 && chunks != 16 && chunks != 32) return fail(c, "pt_set_sample_chunks: 0 (automatic), 1, 2, 4, 8, 16 or 32");
@@ -276,7 +440,7 @@ PT_API int pt_set_sample_chunks(pt_ctx* c, int chunks)
     return 0;
 }
 
-PT_API int pt_set_tuning(pt_ctx* c, int blocks_per_cu, int variant)
+static int set_tuning_one(pt_ctx* c, int blocks_per_cu, int variant)
 {
     if (!c) return fail(nullptr, "pt_set_tuning: null context");
     if (blocks_per_cu < 0 || blocks_per_cu > 16) return fail(c, "pt_set_tuning: blocks_per_cu out of range");
@@ -291,7 +455,7 @@ PT_API int pt_set_tuning(pt_ctx* c, int blocks_per_cu, int variant)
     return 0;
 }
 
-PT_API int pt_set_build_mode(pt_ctx* c, int mode)
+static int set_build_mode_one(pt_ctx* c, int mode)
 {
     if (!c) return fail(nullptr, "pt_set_build_mode: null context");
     if (mode != 0 && mode != 1) return fail(c, "pt_set_build_mode: 0 = Karras LBVH, 1 = PLOC");
@@ -299,10 +463,57 @@ PT_API int pt_set_build_mode(pt_ctx* c, int mode)
     return 0;
 }
 
+PT_API int pt_set_scene(pt_ctx* c, const float* verts_xyzw, size_t n_verts, const uint32_t* idx, size_t n_tris,
+                        const uint32_t* mat_ids, const pt_material* mats, size_t n_mats)
+{
+    if (c && c->multi) return on_every_rank(c, [&](pt_ctx* r, int) { return set_scene_one(r, verts_xyzw, n_verts, idx, n_tris, mat_ids, mats, n_mats); });
+    return set_scene_one(c, verts_xyzw, n_verts, idx, n_tris, mat_ids, mats, n_mats);
+}
+
+PT_API int pt_set_scratch_limit(pt_ctx* c, size_t bytes)
+{
+    if (c && c->multi) return on_every_rank(c, [&](pt_ctx* r, int) { return set_scratch_limit_one(r, bytes); });
+    return set_scratch_limit_one(c, bytes);
+}
+
+PT_API int pt_set_light_mode(pt_ctx* c, int mode)
+{
+    if (c && c->multi) return on_every_rank(c, [&](pt_ctx* r, int) { return set_light_mode_one(r, mode); });
+    return set_light_mode_one(c, mode);
+}
+
+PT_API int pt_set_sample_chunks(pt_ctx* c, int chunks)
+{
+    if (c && c->multi) return on_every_rank(c, [&](pt_ctx* r, int) { return set_sample_chunks_one(r, chunks); });
+    return set_sample_chunks_one(c, chunks);
+}
+
+PT_API int pt_set_tuning(pt_ctx* c, int blocks_per_cu, int variant)
+{
+    if (c && c->multi) return on_every_rank(c, [&](pt_ctx* r, int) { return set_tuning_one(r, blocks_per_cu, variant); });
+    return set_tuning_one(c, blocks_per_cu, variant);
+}
+
+PT_API int pt_set_build_mode(pt_ctx* c, int mode)
+{
+    if (c && c->multi) return on_every_rank(c, [&](pt_ctx* r, int) { return set_build_mode_one(r, mode); });
+    return set_build_mode_one(c, mode);
+}
+
 PT_API const char* pt_variant_name(int variant)
 {
     return (variant >= 0 && variant < ptd::render_variant_count()) ? ptd::render_variant_name(variant) : nullptr;
 }
+
+PT_API const char* pt_variant_kernel(int variant)
+{
+    return (variant >= 0 && variant < ptd::render_variant_count()) ? ptd::render_variant_kernel(variant) : nullptr;
+}
+
+#ifndef ACGPT_KERNEL_SRC_HASH
+#define ACGPT_KERNEL_SRC_HASH "unknown"
+#endif
+PT_API const char* pt_kernel_source_hash(void) { return ACGPT_KERNEL_SRC_HASH; }
 
 PT_API int pt_set_stream(pt_ctx* c, void* s)
 {
@@ -354,14 +565,99 @@ static bool check_fast_div(const ptd::FastDiv& f, uint32_t d, uint32_t n_max)
 PT_API int pt_launch(pt_ctx* c, const pt_params* p) { return pt_launch_frames(c, p, 1u); }
 
 static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames);
+static int launch_frames_single(pt_ctx* c, const pt_params* p, uint32_t n_frames);
+static int launch_frames_multi(pt_ctx* c, const pt_params* p, uint32_t n_frames);
 
 PT_API int pt_launch_frames(pt_ctx* c, const pt_params* p, uint32_t n_frames)
 {
     if (!c || !p) return fail(c, "pt_launch: null argument");
     if (n_frames < 1u || n_frames > 64u) return fail(c, "pt_launch_frames: n_frames must be in [1, 64]");
+    Range range("acgpt: pt_launch_frames");
+    return c->multi ? launch_frames_multi(c, p, n_frames) : launch_frames_single(c, p, n_frames);
+}
+
+// A group's launch: every rank renders its tiles of the same sub-frames into its private buffer (own host thread, own
+// stream), then one reduce to rank 0 and make_color there.  Synchronised on return, like the single-GPU launch.
+static int launch_frames_multi(pt_ctx* c, const pt_params* p, uint32_t n_frames)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    pt_multi* m = c->multi;
+    const int world = (int)m->ranks.size();
+    if (p->width == 0 || p->height == 0) return fail(c, "pt_launch: empty image");
+    if (!p->accumulationBuffer) return fail(c, "pt_launch: accumulationBuffer is null");
+    const size_t pixels = (size_t)p->width * p->height;
+    if (pixels > 0x7FFFFFFFull / 4u) return fail(c, "pt_launch: image too large for the group reduce");
+    // private buffers: (re)allocated zero-filled; a launch that is not the straight continuation of the previous one with
+    // frame > 0 (a restored accumulation) first takes the caller's values for the rank's own pixels
+    const bool fresh = m->accum_pixels != pixels;
+    const bool continues = !fresh && p->accumulationBuffer == m->cont_accum && p->currentFrameIdx == m->cont_frame && p->width == m->cont_w && p->height == m->cont_h;
+    int rc = on_every_rank(c, [&](pt_ctx* r, int i) -> int {
+        CK(r, hipSetDevice(r->device));
+        if (fresh) {
+            if (m->accum[(size_t)i]) { CK(r, hipStreamSynchronize(r->stream)); (void)hipFree(m->accum[(size_t)i]); m->accum[(size_t)i] = nullptr; }
+            CK(r, hipMalloc((void**)&m->accum[(size_t)i], pixels * sizeof(float4)));
+            CK(r, hipMemsetAsync(m->accum[(size_t)i], 0, pixels * sizeof(float4), r->stream));
+        }
+        if (p->currentFrameIdx > 0u && !continues) {
+            CK(r, hipMemcpyAsync(m->accum[(size_t)i], p->accumulationBuffer, pixels * sizeof(float4), hipMemcpyDefault, r->stream));
+            CK(r, ptd::launch_keep_owned(m->accum[(size_t)i], p->width, p->height, i, world, r->stream));
+        }
+        pt_params q = *p;
+        q.accumulationBuffer = (float*)m->accum[(size_t)i];
+        q.frameBuffer = nullptr;
+        r->rank = i; r->world = world;
+        return launch_frames_single(r, &q, n_frames);
+    });
+    if (rc) return rc;
+    m->accum_pixels = pixels;
+    {
+        Range range("acgpt: reduce of the accumulation buffers to rank 0");
+        const auto tr = std::chrono::steady_clock::now();
+        if (m->rehearsal) {         // every buffer lives on the one device: add them there
+            std::vector<const float4*> src(m->accum.begin(), m->accum.end());
+            CK(c, hipSetDevice(c->device));
+            CK(c, ptd::launch_sum_ranks((float4*)p->accumulationBuffer, src.data(), world, (uint32_t)pixels, c->stream));
+            CK(c, hipStreamSynchronize(c->stream));
+        } else {
+            ncclResult_t r = m->rccl.GroupStart();
+            for (int i = 0; i < world && r == ncclSuccess; i++) {
+                CK(c, hipSetDevice(m->ranks[(size_t)i]->device));
+                r = m->rccl.Reduce(m->accum[(size_t)i], i == 0 ? (void*)p->accumulationBuffer : (void*)m->accum[(size_t)i], pixels * 4u, ncclFloat, ncclSum, 0,
+                                   m->comms[(size_t)i], m->ranks[(size_t)i]->stream);
+            }
+            const ncclResult_t e = m->rccl.GroupEnd();
+            if (r == ncclSuccess) r = e;
+            if (r != ncclSuccess) return fail(c, std::string("pt_launch: ncclReduce: ") + m->rccl.GetErrorString(r));
+            for (int i = world - 1; i >= 0; i--) { CK(c, hipSetDevice(m->ranks[(size_t)i]->device)); CK(c, hipStreamSynchronize(m->ranks[(size_t)i]->stream)); }
+        }
+        m->reduce_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tr).count();
+    }
+    if (p->frameBuffer) {
+        CK(c, hipSetDevice(c->device));
+        CK(c, ptd::launch_resolve((const float4*)p->accumulationBuffer, (uint32_t*)p->frameBuffer, (uint32_t)pixels, c->stream));
+        CK(c, hipStreamSynchronize(c->stream));
+    }
+    // the group's counters: rays, paths and pixels summed, the slowest rank's kernel time
+    pt_stats total = m->ranks[0]->stats;
+    for (int i = 1; i < world; i++) {
+        const pt_stats& s = m->ranks[(size_t)i]->stats;
+        total.radiance_rays += s.radiance_rays; total.shadow_rays += s.shadow_rays; total.paths += s.paths; total.culled_rays += s.culled_rays;
+        total.pixels += s.pixels; total.grid_blocks += s.grid_blocks;
+        total.trav_wave_steps += s.trav_wave_steps; total.trav_lane_steps += s.trav_lane_steps;
+        total.shade_wave_rounds += s.shade_wave_rounds; total.shade_lane_rounds += s.shade_lane_rounds;
+        if (s.kernel_ms > total.kernel_ms) total.kernel_ms = s.kernel_ms;
+    }
+    total.launch_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    m->cont_accum = p->accumulationBuffer; m->cont_frame = p->currentFrameIdx + n_frames; m->cont_w = p->width; m->cont_h = p->height;
+    m->group_stats = total;
+    return 0;
+}
+
+static int launch_frames_single(pt_ctx* c, const pt_params* p, uint32_t n_frames)
+{
     // one kernel launch holds one float4 per (pixel, sub-frame) until k_finalize has blended them: batches whose sums
     // would exceed the scratch limit (1 GiB: 32 sub-frames at 1920x1080) run as several launches, same bits
-    const size_t per_frame = (size_t)p->width * p->height * sizeof(float4);
+    const size_t per_frame = (size_t)num_samples(c->world, p->width, p->height) * sizeof(float4);      // this rank's pixel slots
     uint32_t per_launch = per_frame ? (uint32_t)(c->scratch_limit / per_frame) : n_frames;
     if (per_launch < 1u) per_launch = 1u;
     if (per_launch >= n_frames) return launch_batch(c, p, n_frames);
@@ -373,7 +669,7 @@ PT_API int pt_launch_frames(pt_ctx* c, const pt_params* p, uint32_t n_frames)
         q.currentFrameIdx = p->currentFrameIdx + done;
         if (int rc = launch_batch(c, &q, n)) return rc;
         const pt_stats& s = c->stats;
-        total.radiance_rays += s.radiance_rays; total.shadow_rays += s.shadow_rays; total.paths += s.paths;
+        total.radiance_rays += s.radiance_rays; total.shadow_rays += s.shadow_rays; total.paths += s.paths; total.culled_rays += s.culled_rays;
         total.kernel_ms += s.kernel_ms; total.launch_ms += s.launch_ms;
         total.trav_wave_steps += s.trav_wave_steps; total.trav_lane_steps += s.trav_lane_steps;
         total.shade_wave_rounds += s.shade_wave_rounds; total.shade_lane_rounds += s.shade_lane_rounds;
@@ -446,14 +742,18 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
         return fail(c, "pt_launch: image too large for this sample-chunk count and frame batch (2^31 work items)");
     a.total_samples = num_samples(c->world, p->width, p->height) << a.sub_shift;
     a.strip_cols = p->width / (8u * (uint32_t)c->world) + (p->width % (8u * (uint32_t)c->world) == 0 ? 0u : 1u);
-    a.div_cols = make_fast_div(a.strip_cols);
-    a.div_world = make_fast_div((uint32_t)c->world);
-    if (!check_fast_div(a.div_cols, a.strip_cols, num_samples(c->world, p->width, p->height) / 32u) ||
-        !check_fast_div(a.div_world, (uint32_t)c->world, 65536u + (uint32_t)c->world))
-        return fail(c, "pt_launch: internal error (division constants)");
+    if (c->div_width != p->width || c->div_world_n != c->world) {      // the constants depend on (width, world) only: built and verified when those change
+        const ptd::FastDiv dc = make_fast_div(a.strip_cols), dw = make_fast_div((uint32_t)c->world);
+        if (!check_fast_div(dc, a.strip_cols, (65536u / 4u + 1u) * a.strip_cols) ||          // every tile-strip index of the tallest image
+            !check_fast_div(dw, (uint32_t)c->world, 65536u + (uint32_t)c->world))
+            return fail(c, "pt_launch: internal error (division constants)");
+        c->div_cols = dc; c->div_world = dw; c->div_width = p->width; c->div_world_n = c->world;
+    }
+    a.div_cols = c->div_cols;
+    a.div_world = c->div_world;
     a.shard_size = ((a.total_samples + 7u) / 8u + 63u) & ~63u;
-    {   // one float4 per (pixel, sub-frame): what the megakernel hands to k_finalize
-        const size_t need = (size_t)p->width * p->height * n_frames * sizeof(float4);
+    {   // one float4 per (pixel slot of this rank's tile order, sub-frame): what the megakernel hands to k_finalize
+        const size_t need = (size_t)num_samples(c->world, p->width, p->height) * n_frames * sizeof(float4);
         if (need > c->frame_sums_bytes) {
             CK(c, hipStreamSynchronize(c->stream));
             if (c->d_frame_sums) { (void)hipFree(c->d_frame_sums); c->d_frame_sums = nullptr; c->frame_sums_bytes = 0; }
@@ -515,19 +815,21 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
         }
     }
     CK(c, hipMemsetAsync(c->d_queue, 0, 8 * sizeof(uint32_t), c->stream));
-    CK(c, hipMemsetAsync(c->d_counters, 0, (8 + 3 * (size_t)ptd::kMaxTimedWaves + 2056) * sizeof(unsigned long long), c->stream));
+    CK(c, hipMemsetAsync(c->d_counters, 0, (size_t)ptd::kCounterWords * sizeof(unsigned long long), c->stream));
     CK(c, hipEventRecord(c->ev0, c->stream));
-    CK(c, ptd::launch_render(variant, a, grid, c->stream));
+    { Range range("acgpt: render megakernel (launch_batch)"); CK(c, ptd::launch_render(variant, a, grid, c->stream)); }
     CK(c, hipEventRecord(c->ev1, c->stream));
-    CK(c, ptd::launch_finalize(a, c->stream));
-    unsigned long long h[8];
+    { Range range("acgpt: k_finalize"); CK(c, ptd::launch_finalize(a, c->stream)); }
+    unsigned long long h[8], h_culled = 0;
     CK(c, hipMemcpyAsync(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipMemcpyAsync(&h_culled, c->d_counters + ptd::kCulledCounter, sizeof(h_culled), hipMemcpyDeviceToHost, c->stream));
     CK(c, hipStreamSynchronize(c->stream));            // CUDA_SYNC_CHECK, PathTracerMain.cpp:209
     float ms = 0.0f;
     CK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->stats.radiance_rays = h[0];
     c->stats.shadow_rays = h[1];
     c->stats.paths = h[2];
+    c->stats.culled_rays = h_culled;
     c->stats.pixels = (uint32_t)(h[3] / ((unsigned long long)n_frames << a.chunk_shift));
     c->stats.sample_chunks = 1u << a.chunk_shift;
     c->stats.trav_wave_steps = h[4];
@@ -554,7 +856,7 @@ PT_API int pt_resolve_framebuffer(pt_ctx* c, const float* accum, uint8_t* fb, si
 PT_API int pt_get_stats(pt_ctx* c, pt_stats* out)
 {
     if (!c || !out) return fail(c, "pt_get_stats: null argument");
-    *out = c->stats;
+    *out = c->multi ? c->multi->group_stats : c->stats;
     return 0;
 }
 

@@ -8,6 +8,11 @@ namespace ptd {
 constexpr int kRenderThreads = 256;   // 4 waves per workgroup (segment-synchronous variant)
 constexpr uint32_t kRenderFoldSlots = 128;  // fold slots per wave (render_megakernel.hip kFoldSlots)
 constexpr uint32_t kMaxTimedWaves = 16384;   // stats variants stamp start / queue-empty / end per wave behind the 8 counters
+// layout of RenderArgs::counters (64-bit words): [0, 8) ray / path / scheduler counters, [8, 8 + 3 * kMaxTimedWaves) wave stamps,
+// then 2056 words of queue progress and phase times (stats variants), then kTailCounters more launch counters
+constexpr uint32_t kCulledCounter = 8u + 3u * kMaxTimedWaves + 2056u;   // camera rays ended by the scene-box cull (they are part of counters[0] and [2] too)
+constexpr uint32_t kTailCounters = 8u;
+constexpr uint32_t kCounterWords = kCulledCounter + kTailCounters;
 // Variant indices of the product library (render_megakernel.hip kVariants).  pt_set_scene picks one per scene unless
 // pt_set_tuning named one.  fp16 nodes unless the scene has geometry finer than their planes: the mean inflation of a child
 // box by the outward fp16 rounding stays below kHalfInflationLimit (measured break-even on clusters of ever smaller triangles,
@@ -52,7 +57,7 @@ struct RenderArgs {
     uint32_t  sub_shift;       // ceil_log2(n_frames) + chunk_shift
     uint32_t  lcg_mul[32];     // seed of chunk k = lcg_mul[k] * seed0 + lcg_add[k]  (2 * k * chunk_spp LCG steps)
     uint32_t  lcg_add[32];
-    float4*   frame_sums;      // [pixel][n_frames] sums of the sub-frames of a batch (n_frames > 1): k_finalize blends them in order
+    float4*   frame_sums;      // [pixel slot of this rank's tile order][n_frames] sums of the sub-frames of a batch: k_finalize blends them in order
     float*    wave_scratch;    // [wave of the grid][kFoldSlots << chunk_shift][3] partial sums of runs whose group is still open (chunk_shift > 0)
     uint32_t  grant;           // minimum work items taken per queue atomic (1 = exactly what is needed)
     uint32_t  strip_cols;      // tile-strip columns of StaticWorkDistribution for (width, world)
@@ -62,6 +67,7 @@ struct RenderArgs {
 
 int render_variant_count();
 const char* render_variant_name(int variant);
+const char* render_variant_kernel(int variant);   // the instantiation as a kernel trace prints it ("" for experiment variants)
 int render_variant_threads(int variant);
 int render_variant_stack_cap(int variant);      // 0 = the whole stack in LDS
 int render_variant_node_format(int variant);   // 0 fp32 two-child; 7 / 8 / 9 fp16 two-child (min-max / rotated / rotated, flags in the multipliers); experiments: 1/2/4 16-bit grid, 3 four-wide 8-bit
@@ -69,6 +75,8 @@ hipError_t render_occupancy(int variant, uint32_t stack_entries, uint32_t n_node
 hipError_t launch_render(int variant, const RenderArgs& args, uint32_t grid_blocks, hipStream_t stream);
 hipError_t launch_finalize(const RenderArgs& args, hipStream_t stream);
 hipError_t launch_resolve(const float4* accum, uint32_t* fb, uint32_t n, hipStream_t stream);
+hipError_t launch_keep_owned(float4* accum, uint32_t width, uint32_t height, int rank, int world, hipStream_t stream);
+hipError_t launch_sum_ranks(float4* dst, const float4* const* srcs, int n_srcs, uint32_t n, hipStream_t stream);
 hipError_t launch_trace_stream(int fmt, const DeviceScene& sc, uint32_t stack_entries, const float* d_rays, uint32_t n, uint32_t* d_head,
                                float* d_t, uint32_t* d_prim, unsigned long long* d_counters, uint32_t grid_blocks, hipStream_t stream);
 hipError_t trace_stream_occupancy(int fmt, uint32_t stack_entries, int* blocks_per_cu);

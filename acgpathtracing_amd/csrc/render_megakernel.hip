@@ -86,8 +86,6 @@ struct LanePixel {
     f3 result;
 };
 
-__device__ __forceinline__ uint32_t pixel_index(const RenderArgs& A, const LanePixel& lp) { return (lp.pxy >> 16) * A.width + (lp.pxy & 0xFFFFu); }
-
 // n / d for a launch constant d by multiply-high and shifts (Granlund & Montgomery 1994, N = 32: exact for every
 // 32-bit n); capi.hip builds {mul, sh1, sh2} and checks them.  Integer division has no scalar instruction and costs
 // ~40 vector ones; this is 4, and on wave-uniform operands they are scalar.
@@ -211,9 +209,17 @@ __device__ __forceinline__ f3 blend_frame(const f3& prev, const f3& result, uint
 // the sum of one (pixel, sub-frame) is complete: it is parked per (pixel, sub-frame); k_finalize blends the sub-frames of
 // the launch into the accumulation buffer in frame order and applies make_color (the megakernel carries neither: their
 // powf code would be inlined at every place a lane can finish)
-__device__ __forceinline__ void write_frame_sum(const RenderArgs& A, uint32_t pix, uint32_t f, const f3& sum)
+// The sums are indexed by the pixel's slot in this rank's tile order (the inverse of sample_pixel_fast), so a rank that
+// holds 1/world of the tiles holds 1/world of the sums.
+__device__ __forceinline__ uint32_t pixel_slot(const RenderArgs& A, uint32_t pxy)
 {
-    A.frame_sums[(size_t)pix * A.n_frames + f] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+    const uint32_t px = pxy & 0xFFFFu, py = pxy >> 16;
+    const uint32_t strip_x = fast_div(px >> 3, A.div_world);              // px / (8 * world)
+    return (((py >> 2) * A.strip_cols + strip_x) << 5) | ((py & 3u) << 3) | (px & 7u);
+}
+__device__ __forceinline__ void write_frame_sum(const RenderArgs& A, uint32_t pxy, uint32_t f, const f3& sum)
+{
+    A.frame_sums[(size_t)pixel_slot(A, pxy) * A.n_frames + f] = make_float4(sum.x, sum.y, sum.z, 0.0f);
 }
 
 // Two / four consecutive 16-byte loads served by the L2 (sc0: past this CU's L1, whatever an earlier use of the addresses
@@ -241,7 +247,7 @@ __device__ __forceinline__ void finish_runs(const RenderArgs& A, QueueState& q, 
     const uint32_t cs = A.chunk_shift, runs = 1u << cs;
     const uint32_t sub = lp.tag & 0xFFFFu;
     if (cs == 0u) {
-        if (finished) write_frame_sum(A, pixel_index(A, lp), sub, lp.result);
+        if (finished) write_frame_sum(A, lp.pxy, sub, lp.result);
         return;
     }
     const uint32_t slot = lp.tag >> 16;
@@ -276,7 +282,7 @@ __device__ __forceinline__ void finish_runs(const RenderArgs& A, QueueState& q, 
                 sum += mk(p3.x, p3.y, p3.z);
             }
         }
-        write_frame_sum(A, pixel_index(A, lp), sub >> cs, sum);
+        write_frame_sum(A, lp.pxy, sub >> cs, sum);
         book.clear(slot);
         book.free[q.free_top + (uint32_t)popc(folders & below)] = (uint8_t)slot;          // back on the free stack
     }
@@ -296,7 +302,7 @@ __global__ void __launch_bounds__(kFinThreads) k_finalize(const RenderArgs A)
     const uint32_t pix = (uint32_t)y * A.width + (uint32_t)x;
     f3 accum = mk(0.0f);
     if (A.frame > 0u) { const float4 q = A.accum[pix]; accum = mk(q.x, q.y, q.z); }
-    const float4* row = A.frame_sums + (size_t)pix * A.n_frames;
+    const float4* row = A.frame_sums + (size_t)slot * A.n_frames;
     for (uint32_t f = 0; f < A.n_frames; f++) {
         const float4 v = row[f];
         accum = blend_frame(accum, mk(v.x, v.y, v.z), A.spp, A.frame + f);
@@ -526,7 +532,7 @@ k_render_pw(const RenderArgsBox B)
 
     QueueState q; q.shard = xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.grant_g0 = 0; q.grp_pxy = 0xFFFFFFFFu; q.grp_seed = 0; q.free_top = kFoldSlots;
     float* const scratch = A.wave_scratch + 3u * (size_t)(blockIdx.x * (THREADS / 64) + wave) * ((size_t)kFoldSlots << A.chunk_shift);
-    unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0;
+    unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0, n_culled = 0;
     unsigned long long n_steps = 0, n_lane_steps = 0, n_rounds = 0, n_lane_rounds = 0;
     // STATS only: 100 MHz stamps of this wave's start, of the moment it found the queue empty, and of its end
     unsigned long long t_start = 0, t_drain = 0, t_phase = 0, t_in_shade = 0, t_refill = 0, t_finish = 0, t_newpath = 0, t_mark = 0;
@@ -649,7 +655,7 @@ k_render_pw(const RenderArgsBox B)
         if (vote(my_culled != 0u) != 0ull) {                           // wave sum of the per-lane counts, bit plane by bit plane
             unsigned long long sum = 0ull;
             for (uint32_t b = 0; vote((my_culled >> b) != 0u) != 0ull; b++) sum += (unsigned long long)popc(vote(((my_culled >> b) & 1u) != 0u)) << b;
-            n_radiance += sum; n_paths += sum;
+            n_radiance += sum; n_paths += sum; n_culled += sum;
         }
         if (STATS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); t_newpath += now - t_mark; }
         if (vote(lp.alive) == 0ull) { if (q.shards_left == 0u && q.res_count == 0u && vote(fin_pending) == 0ull) break; else continue; }
@@ -922,6 +928,7 @@ k_render_pw(const RenderArgsBox B)
         atomicAdd(&A.counters[5], n_lane_steps);
         atomicAdd(&A.counters[6], n_rounds);
         atomicAdd(&A.counters[7], n_lane_rounds);
+        if (n_culled) atomicAdd(&A.counters[kCulledCounter], n_culled);
         if (STATS) {
             const uint32_t w = blockIdx.x * (THREADS / 64) + wave;
             if (w < kMaxTimedWaves) {
@@ -941,6 +948,43 @@ __global__ void k_resolve(const float4* __restrict__ accum, uint32_t* __restrict
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { const float4 a = accum[i]; fb[i] = make_color(mk(a.x, a.y, a.z)); }
+}
+
+// multi-GPU group (capi.hip pt_multi): a rank's private accumulation buffer holds its own pixels and zero elsewhere.
+// k_keep_owned re-establishes that after the caller's buffer was copied in (a restored accumulation); the owner of a pixel is
+// the inverse of StaticWorkDistribution::getSamplePixel (sutil/WorkDistribution.h:60-81).
+__global__ void k_keep_owned(float4* __restrict__ accum, uint32_t width, uint32_t n, int rank, int world)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t x = i % width, y = i / width;
+    const int col = (int)((x >> 3) % (uint32_t)world), row = (int)((y >> 2) % (uint32_t)world);
+    const int owner = (col - row + world) % world;
+    if (owner != rank) accum[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+// rehearsal of the reduce on a one-GPU box (all ranks' buffers on one device): dst = srcs[0] + srcs[1] + ...
+struct SumSources { const float4* p[16]; int n; };
+__global__ void k_sum_ranks(float4* __restrict__ dst, const SumSources src, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 a = src.p[0][i];
+    for (int k = 1; k < src.n; k++) { const float4 b = src.p[k][i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    dst[i] = a;
+}
+hipError_t launch_keep_owned(float4* accum, uint32_t width, uint32_t height, int rank, int world, hipStream_t stream)
+{
+    const uint32_t n = width * height;
+    k_keep_owned<<<(n + 255) / 256, 256, 0, stream>>>(accum, width, n, rank, world);
+    return hipGetLastError();
+}
+hipError_t launch_sum_ranks(float4* dst, const float4* const* srcs, int n_srcs, uint32_t n, hipStream_t stream)
+{
+    if (n_srcs < 1 || n_srcs > 16) return hipErrorInvalidValue;
+    SumSources s; s.n = n_srcs;
+    for (int k = 0; k < 16; k++) s.p[k] = k < n_srcs ? srcs[k] : nullptr;
+    k_sum_ranks<<<(n + 255) / 256, 256, 0, stream>>>(dst, s, n);
+    return hipGetLastError();
 }
 
 hipError_t launch_finalize(const RenderArgs& args, hipStream_t stream)
@@ -1282,23 +1326,27 @@ hipError_t trace_stream_occupancy(int fmt, uint32_t stack_entries, int* blocks_p
 // ---- host-side launchers ------------------------------------------------------------------
 typedef void (*RenderKernel)(const RenderArgsBox);
 
-struct VariantDesc { RenderKernel k; int threads; int node_fmt; const char* name; int stack_cap = 0; };
+struct VariantDesc { RenderKernel k; int threads; int node_fmt; const char* name; int stack_cap = 0; const char* kernel = ""; };
 
 // Render kernel variants.  0: segment-synchronous (fp32 nodes).  Others: persistent traversal
-// <SHADE_K, LEAF_K, NODE_FMT, THREADS, MINW, STATS, DIAG, INNER, LEAVES>.  The product library carries the variants a user
-// can meaningfully pick (indices fixed: render_megakernel.h); everything that was measured on the way and lost is
+// <SHADE_K, LEAF_K, NODE_FMT, THREADS, MINW, STATS, DIAG, INNER, LEAVES, LIGHTS, STACK_CAP>.  The product library carries the
+// variants a user can meaningfully pick (indices fixed: render_megakernel.h); everything that was measured on the way and lost is
 // compiled only with -DACGPT_EXPERIMENTS (acgpathtracing_amd/_build.py build_hip(experiments=True), tools/sweep_variants.py).
+// PW(...): the instantiation and its name as a kernel trace prints it (all eleven arguments spelled out), so that a profile
+// can be tied to the variant that ran (pt_variant_kernel, bench.py).
+#define PW(...) k_render_pw<__VA_ARGS__>
+#define PWN(...) "k_render_pw<" #__VA_ARGS__ ">"
 static const VariantDesc kVariants[] = {
-    {k_render, 256, 0, "sync fp32-nodes"},
-    {k_render_pw<44, 16, 0, 256, 4, false, 0, 2, 2>, 256, 0, "pw K44 L16 fp32 nodes w4, register stack top, two visits and two triangle tests per loop trip"},
-    {k_render_pw<44, 16, 0, 256, 4, true, 0, 2, 2>, 256, 0, "pw K44 L16 fp32 nodes + scheduler stats"},
-    {k_render_pw<48, 8, 0, 256, 4, false, 0, 2>, 256, 0, "pw K48 L8 fp32 nodes w4, two visits per loop trip (large scenes whose fp16 planes would be too coarse)"},
-    {k_render_pw<48, 12, 0, 256, 4, false, 3, 1>, 256, 0, "FAST-MATH hardware sin/cos + algebraic acos in the cosine-weighted sampler (opt-in; other bits than the default)"},
-    {k_render_pw<44, 16, 8, 256, 4, false, 0, 3, 2>, 256, 8, "pw K44 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes, w4, three visits and two triangle tests per loop trip"},
-    {k_render_pw<44, 16, 9, 256, 4, true, 0, 5, 2>, 256, 9, "pw K44 L16 fp16 sign-rotated nodes, five visits per trip + scheduler stats (the default kernel's loop at four waves)"},
-    {k_render_pw<44, 16, 9, 256, 5, false, 0, 5, 2>, 256, 9, "pw K44 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes with the rotate amounts in the multipliers' low bits, FIVE waves per SIMD (96 registers), five visits and two triangle tests per loop trip"},
-    {k_render_pw<44, 16, 9, 256, 4, false, 0, 5, 2, true>, 256, 9, "LIGHTS scene-driven area lights + MIS (light mode 1, opt-in: not the reference's estimator), fp16 sign-rotated nodes w4"},
-    {k_render_pw<44, 16, 9, 256, 5, false, 0, 5, 2, false, 28>, 256, 9, "pw K44 L16 fp16 sign-rotated nodes, five waves per SIMD for deep trees: 28 stack entries per lane in LDS, deeper ones in global memory", 28},
+    {k_render, 256, 0, "sync fp32-nodes", 0, "k_render"},
+    {PW(44, 16, 0, 256, 4, false, 0, 2, 2, false, 0), 256, 0, "pw K44 L16 fp32 nodes w4, register stack top, two visits and two triangle tests per loop trip", 0, PWN(44, 16, 0, 256, 4, false, 0, 2, 2, false, 0)},
+    {PW(44, 16, 0, 256, 4, true, 0, 2, 2, false, 0), 256, 0, "pw K44 L16 fp32 nodes + scheduler stats", 0, PWN(44, 16, 0, 256, 4, true, 0, 2, 2, false, 0)},
+    {PW(48, 8, 0, 256, 4, false, 0, 2, 1, false, 0), 256, 0, "pw K48 L8 fp32 nodes w4, two visits per loop trip (large scenes whose fp16 planes would be too coarse)", 0, PWN(48, 8, 0, 256, 4, false, 0, 2, 1, false, 0)},
+    {PW(48, 12, 0, 256, 4, false, 3, 1, 1, false, 0), 256, 0, "FAST-MATH hardware sin/cos + algebraic acos in the cosine-weighted sampler (opt-in; other bits than the default)", 0, PWN(48, 12, 0, 256, 4, false, 3, 1, 1, false, 0)},
+    {PW(44, 16, 8, 256, 4, false, 0, 3, 2, false, 0), 256, 8, "pw K44 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes, w4, three visits and two triangle tests per loop trip", 0, PWN(44, 16, 8, 256, 4, false, 0, 3, 2, false, 0)},
+    {PW(44, 16, 9, 256, 4, true, 0, 5, 2, false, 0), 256, 9, "pw K44 L16 fp16 sign-rotated nodes, five visits per trip + scheduler stats (the default kernel's loop at four waves)", 0, PWN(44, 16, 9, 256, 4, true, 0, 5, 2, false, 0)},
+    {PW(44, 16, 9, 256, 5, false, 0, 5, 2, false, 0), 256, 9, "pw K44 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes with the rotate amounts in the multipliers' low bits, FIVE waves per SIMD (96 registers), five visits and two triangle tests per loop trip", 0, PWN(44, 16, 9, 256, 5, false, 0, 5, 2, false, 0)},
+    {PW(44, 16, 9, 256, 4, false, 0, 5, 2, true, 0), 256, 9, "LIGHTS scene-driven area lights + MIS (light mode 1, opt-in: not the reference's estimator), fp16 sign-rotated nodes w4", 0, PWN(44, 16, 9, 256, 4, false, 0, 5, 2, true, 0)},
+    {PW(44, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "pw K44 L16 fp16 sign-rotated nodes, five waves per SIMD for deep trees: 28 stack entries per lane in LDS, deeper ones in global memory", 28, PWN(44, 16, 9, 256, 5, false, 0, 5, 2, false, 28)},
 #ifdef ACGPT_EXPERIMENTS
     {k_render_pw<40, 8, 0, 256, 4, false, 0, 1>, 256, 0, "pw K40 L8 fp32 w4, register stack top"},
     {k_render_pw<48, 8, 0, 256, 4, false>, 256, 0, "pw K48 L8 fp32 w4, LDS-only stack"},
@@ -1382,6 +1430,7 @@ const char* render_variant_name(int v) { return (v >= 0 && v < render_variant_co
 int render_variant_node_format(int v) { return (v >= 0 && v < render_variant_count()) ? kVariants[v].node_fmt : -1; }
 int render_variant_threads(int v) { return (v >= 0 && v < render_variant_count()) ? kVariants[v].threads : 0; }
 int render_variant_stack_cap(int v) { return (v >= 0 && v < render_variant_count()) ? kVariants[v].stack_cap : 0; }
+const char* render_variant_kernel(int v) { return (v >= 0 && v < render_variant_count()) ? kVariants[v].kernel : ""; }
 
 static size_t variant_lds(const VariantDesc& d, uint32_t stack_entries, uint32_t n_nodes)
 {

@@ -6,10 +6,35 @@ sutil/WorkDistribution.h:60-81 assigns to it into a ZERO-INITIALISED full-size f
 `reduce(SUM)` to rank 0 (RCCL over xGMI with backend "nccl", gloo on CPU in the tests) then yields
 exactly the single-GPU image: every pixel receives one non-zero term, and x + 0 + ... + 0 is exact.
 """
+import contextlib
+import ctypes
 import os
 
 import torch
 import torch.distributed as dist
+
+_roctx = None
+
+
+@contextlib.contextmanager
+def roctx_range(name):
+    """ROCTx range (shows up in `rocprofv3 --marker-trace`); a no-op without the marker library."""
+    global _roctx
+    if _roctx is None:
+        _roctx = False
+        for lib in ("librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4"):
+            try:
+                _roctx = ctypes.CDLL(lib)
+                break
+            except OSError:
+                pass
+    if _roctx:
+        _roctx.roctxRangePushA(name.encode())
+    try:
+        yield
+    finally:
+        if _roctx:
+            _roctx.roctxRangePop()
 
 
 def env_rank_world():
@@ -35,7 +60,8 @@ def reduce_accumulation(accum, dst=0):
     """Sum the per-rank accumulation buffers onto `dst`.  `accum` is a float32 tensor [H, W, 4]
     (CUDA for RCCL, CPU for gloo) that is zero outside this rank's tiles.  In place on dst."""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
+        with roctx_range("acgpt: reduce of the accumulation buffers to rank 0"):
+            dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
     return accum
 
 

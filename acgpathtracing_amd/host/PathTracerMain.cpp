@@ -9,6 +9,13 @@
 //              [--max-depth 4] [--direct-lighting] [--importance-sampling] [--device 0]
 //              [--keys "0,1,UP,UP,R"] [--out frame.png] [--dump-every k] [--zero-copy]
 //              [--orbit dx,dy] [--zoom n] [--sample-chunks c] [--build-mode 0|1]
+//              [--gpus N] [--multi] [--save-accum file] [--restore-accum file]
+//
+// --gpus N renders on devices 0..N-1 of the node through ONE context (pt_create_multi): pixel tiles of
+// sutil/WorkDistribution.h per device, one RCCL reduce of the accumulation per launch — the reference's dormant multi-GPU
+// path, behind the same functions.  --save-accum / --restore-accum write and read the progressive state of the reference
+// (params.accumulationBuffer + currentFrameIdx, pathTracerPrograms.cu:803-811): a restored run continues the running mean
+// where the saved one stopped, bit for bit.
 //
 // --keys replays the reference's key handler (PathTracerMain.cpp:100-141) between frames, one key
 // per frame: 0 = direct lighting, 1 = importance sampling, UP/DOWN = max depth +-1 in [1,28],
@@ -48,6 +55,8 @@ struct PathTracerState {                                // :71-93
     pt_ctx* context = nullptr;
     pt_params params = {};
     int device = 0;
+    int gpus = 1;                                       // > 1: one context over devices 0..gpus-1
+    bool multi = false;                                 // --multi: the group context even for one device (its RCCL reduce then runs with one rank)
 };
 
 static bool keyCallback(PathTracerState& state, const std::string& key)   // :100-141; false = quit
@@ -132,7 +141,13 @@ static void initCamera()                                                 // :228
 
 static void createDeviceContext(PathTracerState& state)                  // :240-258
 {
-    if (pt_create(&state.context, state.device) != 0) throw Exception(std::string("createDeviceContext: ") + pt_last_error(nullptr));
+    if (state.gpus > 1 || state.multi) {
+        // devices device, device + 1, ...; as a rehearsal on a one-GPU box (ACGPT_REHEARSE_SAME_GPU=1) every rank shares `device`
+        const char* reh = getenv("ACGPT_REHEARSE_SAME_GPU");
+        std::vector<int> ids((size_t)state.gpus);
+        for (int i = 0; i < state.gpus; i++) ids[(size_t)i] = (reh && reh[0] == '1') ? state.device : state.device + i;
+        if (pt_create_multi(&state.context, ids.data(), state.gpus) != 0) throw Exception(std::string("createDeviceContext: ") + pt_last_error(nullptr));
+    } else if (pt_create(&state.context, state.device) != 0) throw Exception(std::string("createDeviceContext: ") + pt_last_error(nullptr));
     makeContextCurrent(state.context);      // OutputBuffer(type, w, h) allocates here, as CUDAOutputBuffer does on the current device
 }
 
@@ -146,6 +161,35 @@ static void buildTheAccelarationStructure(PathTracerState& state, const TinyObjW
                                          h_mat_indices.data(), reinterpret_cast<const pt_material*>(materials.data()), materials.size()));
 }
 
+// The progressive state of the reference is the accumulation buffer and the frame index (pathTracerPrograms.cu:803-811).
+// File: "ACGPTACC" | width | height | frames accumulated | float4[width * height]
+static void saveAccumulation(PathTracerState& state, const std::string& path)
+{
+    const size_t n = (size_t)state.params.width * state.params.height * 4;
+    std::vector<float> host(n);
+    PT_CHECK(state.context, pt_copy_to_host(state.context, host.data(), state.params.accumulationBuffer, n * sizeof(float)));
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) throw Exception("cannot write " + path);
+    const uint32_t hdr[3] = {state.params.width, state.params.height, state.params.currentFrameIdx};
+    const bool ok = fwrite("ACGPTACC", 1, 8, f) == 8 && fwrite(hdr, 4, 3, f) == 3 && fwrite(host.data(), sizeof(float), n, f) == n;
+    fclose(f);
+    if (!ok) throw Exception("short write to " + path);
+}
+static void restoreAccumulation(PathTracerState& state, const std::string& path)
+{
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw Exception("cannot read " + path);
+    char magic[8]; uint32_t hdr[3] = {0, 0, 0};
+    const size_t n = (size_t)state.params.width * state.params.height * 4;
+    std::vector<float> host(n);
+    const bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "ACGPTACC", 8) == 0 && fread(hdr, 4, 3, f) == 3 &&
+                    hdr[0] == state.params.width && hdr[1] == state.params.height && fread(host.data(), sizeof(float), n, f) == n;
+    fclose(f);
+    if (!ok) throw Exception(path + ": not an accumulation dump of a " + std::to_string(state.params.width) + "x" + std::to_string(state.params.height) + " image");
+    PT_CHECK(state.context, pt_copy_to_device(state.context, state.params.accumulationBuffer, host.data(), n * sizeof(float)));
+    state.params.currentFrameIdx = hdr[2];
+}
+
 static void CleanAllTheThings(PathTracerState& state)                    // :629-646
 {
     if (state.params.accumulationBuffer) pt_device_free(state.context, state.params.accumulationBuffer);
@@ -155,7 +199,7 @@ static void CleanAllTheThings(PathTracerState& state)                    // :629
 
 int main(int argc, char** argv)
 {
-    std::string objfilepath, out = "frame.png", keys;
+    std::string objfilepath, out = "frame.png", keys, save_accum, restore_accum;
     int32_t width = 512, height = 512, frames = 8, dump_every = 0;
     bool zero_copy = false;
     int orbit_dx = 0, orbit_dy = 0, zoom_steps = 0, sample_chunks = 0, build_mode = 1, fuse = 1, light_mode = 0;
@@ -175,6 +219,10 @@ int main(int argc, char** argv)
         else if (a == "--direct-lighting") state.params.useDirectLighting = true;
         else if (a == "--importance-sampling") state.params.useImportanceSampling = true;
         else if (a == "--device") state.device = atoi(next());
+        else if (a == "--gpus") state.gpus = std::max(1, atoi(next()));
+        else if (a == "--multi") state.multi = true;
+        else if (a == "--save-accum") save_accum = next();
+        else if (a == "--restore-accum") restore_accum = next();
         else if (a == "--keys") keys = next();
         else if (a == "--out") out = next();
         else if (a == "--dump-every") dump_every = atoi(next());
@@ -223,6 +271,11 @@ int main(int argc, char** argv)
         std::cout << "Acceleration Structure Built" << std::endl;
         initializeTheLaunch(state);
         std::cout << "Launch Initialized" << std::endl;
+        if (!restore_accum.empty()) {
+            restoreAccumulation(state, restore_accum);
+            std::cout << "Accumulation restored: " << state.params.currentFrameIdx << " frames" << std::endl;
+        }
+        if (state.gpus > 1 || state.multi) std::cout << "Devices: " << pt_device_count(state.context) << std::endl;
         uint64_t rays = 0;
         {
             OutputBuffer<uchar4> output_buffer(zero_copy ? OutputBufferType::ZERO_COPY : OutputBufferType::DEVICE,
@@ -255,6 +308,7 @@ int main(int argc, char** argv)
             std::cout << std::endl;
             if (!saveImage(out, reinterpret_cast<const uint8_t*>(output_buffer.getHostPointer()), width, height))
                 std::cerr << "could not write " << out << std::endl;
+            if (!save_accum.empty()) saveAccumulation(state, save_accum);
         }
         CleanAllTheThings(state);
         if (frame_counter > 0) avg_ms /= frame_counter;

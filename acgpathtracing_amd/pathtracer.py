@@ -238,10 +238,16 @@ class PathTracerState:
         self._accum_bytes = 0
 
 
-def createDeviceContext(state, device_id=0):
+def createDeviceContext(state, device_id=0, device_ids=None):
+    """device_ids (a list): ONE context over several GPUs of the node (pt_create_multi) — pixel tiles per device and an
+    RCCL reduce of the accumulation per launch behind the same functions; device_id alone: the reference's one device."""
     L = _native.hip()
     ctx = C.c_void_p()
-    rc = L.pt_create(C.byref(ctx), int(device_id))
+    if device_ids is not None:
+        ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
+        rc = L.pt_create_multi(C.byref(ctx), ids, len(device_ids))
+    else:
+        rc = L.pt_create(C.byref(ctx), int(device_id))
     if rc != 0:
         msg = L.pt_last_error(None)
         raise PathTracerError("createDeviceContext failed: %s" % (msg.decode() if msg else "unknown"))
@@ -356,6 +362,30 @@ def readAccumulation(state):
     return out
 
 
+def saveAccumulation(state, filename):
+    """The progressive state of the reference — params.accumulationBuffer and currentFrameIdx
+    (pathTracerPrograms.cu:803-811) — as a file; same format as acgpt_main --save-accum."""
+    acc = readAccumulation(state)
+    with open(filename, "wb") as fh:
+        fh.write(b"ACGPTACC")
+        fh.write(np.array([state.params.width, state.params.height, state.params.currentFrameIdx], np.uint32).tobytes())
+        fh.write(acc.tobytes())
+
+
+def restoreAccumulation(state, filename):
+    """Continue a saved run: fills params.accumulationBuffer and sets currentFrameIdx to the frames accumulated so far."""
+    h, w = int(state.params.height), int(state.params.width)
+    with open(filename, "rb") as fh:
+        blob = fh.read()
+    hdr = np.frombuffer(blob[8:20], np.uint32) if len(blob) >= 20 else None
+    if blob[:8] != b"ACGPTACC" or hdr is None or int(hdr[0]) != w or int(hdr[1]) != h or len(blob) != 20 + h * w * 16:
+        raise PathTracerError("%s is not an accumulation dump of a %dx%d image" % (filename, w, h))
+    acc = np.frombuffer(blob[20:], np.float32).copy()
+    _check(state.context, _native.hip().pt_copy_to_device(state.context, state.params.accumulationBuffer, acc.ctypes.data, acc.nbytes),
+           "restoreAccumulation")
+    state.params.currentFrameIdx = int(hdr[2])
+
+
 def saveImage(filename, rgba):
     """sutil::saveImage conventions (sutil/sutil.cpp:542-655): `rgba` is uint8 [height, width, 4] with row 0
     at the BOTTOM; the file is written top-down; alpha is dropped.  Suffix .ppm or .png."""
@@ -397,7 +427,7 @@ def CleanAllTheThings(state):
 
 
 def setup(obj_path, width=512, height=512, max_depth=4, direct_lighting=False, importance_sampling=False,
-          spp=samples_per_launch, device_id=0, build_mode=None):
+          spp=samples_per_launch, device_id=0, build_mode=None, device_ids=None):
     """The body of main() up to the frame loop (PathTracerMain.cpp:650-684) as one call."""
     obj = TinyObjWrapper(obj_path)
     if not obj.dataLoaded:
@@ -412,7 +442,7 @@ def setup(obj_path, width=512, height=512, max_depth=4, direct_lighting=False, i
     state.params.cameraEye = _f3(cam.eye())
     U, V, W = cam.UVWFrame()
     state.params.cameraU, state.params.cameraV, state.params.cameraW = _f3(U), _f3(V), _f3(W)
-    createDeviceContext(state, device_id)
+    createDeviceContext(state, device_id, device_ids)
     if build_mode is not None:
         _check(state.context, _native.hip().pt_set_build_mode(state.context, int(build_mode)), "pt_set_build_mode")
     buildTheAccelarationStructure(state, obj)

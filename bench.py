@@ -28,9 +28,13 @@ Cornell-class input: 140 KB) or the Infinity Cache is served on chip, and the SU
 (B_ray = 64*ceil(log2 T) + 64 bytes per ray + 36*W*H per step) then describes cache traffic, not HBM —
 it is reported as `hbm_model` and never as `frac`.  For those scenes `bound` is "valu": achieved =
 algorithmic fp32 flops (F_ray = 48*ceil(log2 T) + 168 per ray) over the kernel's
-HIP-event time, peak = 157.3 TFLOP/s fp32 vector.  `traffic` = measured HBM bytes per kernel launch and
-`measured` = the unit-busy fractions, both from the committed PMC summary of this config's default
-command (profiles/, separate --pmc passes, gfx950 FETCH_SIZE correction), whatever --steps is.
+HIP-event time, peak = 157.3 TFLOP/s fp32 vector.  Flops and bytes are priced on the rays that are
+TRAVERSED: camera rays that end at the scene's bounding box (pt_stats.culled_rays; they are part of the
+Mray/s figure, SURVEY.md §8d counts every radiance segment) carry none.  `traffic` = measured HBM bytes per
+kernel launch and `measured` = the unit-busy fractions, both from the committed PMC summary of this
+config's default command (profiles/, separate --pmc passes, gfx950 FETCH_SIZE correction) — attached only
+if that profile was taken on the kernel that ran here: same instantiation (pt_variant_kernel) and same
+kernel sources (pt_kernel_source_hash); a stale profile drops out.
 `cpu_baseline` times the CPU oracle (oracle/, scalar C++ restatement, std::thread over the host cores)
 on a bounded sample of the same workload — reported, not the target.
 """
@@ -165,7 +169,12 @@ def pmc_summary(config):
         return None, None
 
 
-def roofline_block(a, info, world, fuse, kernel_ms, rays_per_launch, steps_per_launch, variant_name):
+GATHER_PEAK_GBS = 7400.0        # MI355X_MICROARCH.md: measured random-gather rate out of the Infinity Cache (7.4-7.9 TB/s, 151 MB table)
+
+
+def roofline_block(a, info, world, fuse, kernel_ms, traced_per_launch, counted_per_launch, steps_per_launch, variant_name, variant_kernel, source_hash):
+    """traced_per_launch: rays that enter the BVH loop (radiance + shadow - culled); counted_per_launch: every ray of the
+    SURVEY.md 8d definition (what `value` counts)."""
     T = max(2, info.n_tris)
     levels = math.ceil(math.log2(T))
     b_ray = 64 * levels + 64
@@ -173,47 +182,70 @@ def roofline_block(a, info, world, fuse, kernel_ms, rays_per_launch, steps_per_l
     k_avg_ms = sum(kernel_ms) / max(1, len(kernel_ms))
     ksec = k_avg_ms * 1e-3
     my_pixels = a.width * a.height / world
-    algo_bytes = rays_per_launch * b_ray + 36.0 * my_pixels * steps_per_launch
-    algo_flops = rays_per_launch * f_ray
+    algo_bytes = traced_per_launch * b_ray + 36.0 * my_pixels * steps_per_launch
+    algo_flops = traced_per_launch * f_ray
     half = "fp16" in variant_name                    # the node array the kernel that ran walks: 32-byte fp16 or 64-byte fp32 nodes
     scene_bytes = int(info.half_node_bytes if half else info.node_bytes) + int(info.tri_bytes)
     kernel_b_ray = (32 if half else 64) * levels + 48   # what this kernel's formats move per ray of the SURVEY model: one node per level + one triangle record
-    kernel_bytes = rays_per_launch * kernel_b_ray + 36.0 * my_pixels * steps_per_launch
+    kernel_bytes = traced_per_launch * kernel_b_ray + 36.0 * my_pixels * steps_per_launch
     kernel_gbs = kernel_bytes / ksec / 1e9 if ksec > 0 else 0.0
     resident = "L2" if scene_bytes <= L2_BYTES else ("Infinity Cache" if scene_bytes <= MALL_BYTES else "HBM")
     model_gbs = algo_bytes / ksec / 1e9 if ksec > 0 else 0.0
     valu_tf = algo_flops / ksec / 1e12 if ksec > 0 else 0.0
+    valu_tf_counted = counted_per_launch * f_ray / ksec / 1e12 if ksec > 0 else 0.0
     summ, src = pmc_summary(a.config)
     default_cmd = (a.scene == {2: "cornell_box_diffuse.obj", 3: "cornell_box.obj", 5: "stress_1m.obj"}[a.config]
                    and (a.width, a.height, a.spp) == (WIDTH, HEIGHT, SPP_PER_LAUNCH) and world == 1 and a.variant < 0
                    and not a.blocks_per_cu and a.fuse == 8 and a.chunks == 0)
-    traffic, measured = None, None
+    traffic, measured, fabric, dropped = None, None, None, None
     if summ and default_cmd:
-        der = summ.get("derived", {})
-        traffic = der.get("hbm_bytes_per_launch")
-        measured = {"source": src, "kernel": summ.get("kernel_stats", {}).get("name"),
-                    "kernel_ms_avg_rocprof": summ.get("kernel_stats", {}).get("avg_ms"),
-                    "steps_per_launch_profiled": summ.get("steps_per_kernel_launch", 8),
-                    "ta_busy": der.get("ta_busy_frac(256 TAs)"),
-                    "valu_issue_busy": der.get("valu_issue_busy_frac(2cyc/instr,1024 SIMDs)"),
-                    "lane_utilisation": der.get("valu_lane_utilisation"),
-                    "l2_hit": der.get("l2_hit_rate"), "l1_miss_per_access": der.get("l1_miss_per_access"),
-                    "hbm_GBps": (traffic / (summ["kernel_stats"]["avg_ms"] * 1e-3) / 1e9) if traffic and summ.get("kernel_stats") else None}
-    r = {"kernel": variant_name, "kernel_ms_avg": k_avg_ms, "scene_bytes": scene_bytes, "scene_resident_in": resident,
+        prof_kernel = summ.get("kernel_stats", {}).get("name", "")
+        same_kernel = bool(variant_kernel) and variant_kernel in prof_kernel
+        same_source = summ.get("kernel_source_hash") == source_hash
+        if same_kernel and same_source:
+            der = summ.get("derived", {})
+            traffic = der.get("hbm_bytes_per_launch")
+            prof_ms = summ.get("kernel_stats", {}).get("avg_ms")
+            measured = {"source": src, "kernel": prof_kernel, "kernel_source_hash": source_hash,
+                        "kernel_ms_avg_rocprof": prof_ms,
+                        "steps_per_launch_profiled": summ.get("steps_per_kernel_launch", 8),
+                        "ta_busy": der.get("ta_busy_frac(256 TAs)"),
+                        "valu_issue_busy": der.get("valu_issue_busy_frac(2cyc/instr,1024 SIMDs)"),
+                        "lane_utilisation": der.get("valu_lane_utilisation"),
+                        "l2_hit": der.get("l2_hit_rate"), "l1_miss_per_access": der.get("l1_miss_per_access"),
+                        "hbm_GBps": (traffic / (prof_ms * 1e-3) / 1e9) if traffic and prof_ms else None}
+            if resident == "Infinity Cache" and traffic and prof_ms:
+                # a scene the Infinity Cache holds: what moves between L2 and the fabric is gather traffic, priced against the
+                # guide's measured gather rate out of that cache, not against HBM
+                gbs = traffic / (prof_ms * 1e-3) / 1e9
+                fabric = {"GBps": gbs, "peak": GATHER_PEAK_GBS, "frac": gbs / GATHER_PEAK_GBS,
+                          "note": "L2 <-> fabric bytes of the profiled launch over its rocprof time, against the 7.4-7.9 TB/s random-gather rate of the Infinity Cache (MI355X_MICROARCH.md)"}
+        else:
+            dropped = {"source": src, "reason": ("profiled kernel %r is not the %r that ran" % (prof_kernel[:120], variant_kernel)) if not same_kernel
+                       else ("profile taken on kernel sources %s, this library is built from %s" % (summ.get("kernel_source_hash"), source_hash))}
+    r = {"kernel": variant_name, "kernel_instantiation": variant_kernel, "kernel_source_hash": source_hash,
+         "kernel_ms_avg": k_avg_ms, "scene_bytes": scene_bytes, "scene_resident_in": resident,
          "traffic": traffic, "measured": measured,
          "traffic_note": ("bytes between L2 and the fabric per kernel launch (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section); "
                           + ("reads that the 256 MB Infinity Cache serves are included: an upper bound on HBM traffic" if resident == "Infinity Cache"
                              else "HBM traffic")),
+         "rays_priced": "traversed rays only (radiance + shadow - culled camera rays)",
          "hbm_model": {"algorithmic_bytes_per_ray": b_ray, "algorithmic_bytes_per_launch": algo_bytes, "GBps": model_gbs,
                        "note": "SURVEY.md 8d byte model; for a cache-resident scene these bytes are served by L1/L2/Infinity Cache, so this is not an HBM fraction"},
          "valu_model": {"algorithmic_flops_per_ray": f_ray, "TFLOPs": valu_tf, "frac_of_fp32_vector_peak": valu_tf / FP32_PEAK_TFLOPS}}
+    if dropped:
+        r["profile_dropped"] = dropped
+    if fabric:
+        r["fabric"] = fabric
     if resident == "HBM":
         # priced with the bytes of the node format that ran (an fp16 node is half the SURVEY model's 64 B), so that a compact
         # format does not read as bandwidth
         r.update({"bound": "hbm", "achieved": kernel_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kernel_gbs / HBM_PEAK_GBS,
                   "algorithmic_bytes_per_ray_this_kernel": kernel_b_ray})
     else:
-        r.update({"bound": "valu", "achieved": valu_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": valu_tf / FP32_PEAK_TFLOPS})
+        r.update({"bound": "valu", "achieved": valu_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": valu_tf / FP32_PEAK_TFLOPS,
+                  "frac_entering_scene": valu_tf / FP32_PEAK_TFLOPS,
+                  "frac_counting_culled_rays": valu_tf_counted / FP32_PEAK_TFLOPS})
     return r
 
 
@@ -260,7 +292,7 @@ def main():
     assert L.pt_set_sample_chunks(state.context, a.chunks) == 0
     assert L.pt_set_stream(state.context, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
     if a.blocks_per_cu or a.variant >= 0:
-        assert L.pt_set_tuning(state.context, a.blocks_per_cu, max(a.variant, 0)) == 0
+        assert L.pt_set_tuning(state.context, a.blocks_per_cu, a.variant if a.variant >= 0 else -1) == 0
     info = pt.getBvhInfo(state)
 
     fuse = max(1, min(a.fuse, 64, a.steps))
@@ -288,14 +320,14 @@ def main():
     # ---- timed region ---------------------------------------------------------------------------
     D.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    rays = shadow = paths = 0
+    rays = shadow = paths = culled = 0
     kernel_ms = []
     last_stats = None
     k = 0
     while k < a.steps:
         n = min(fuse, a.steps - k)
         s = launch(k, n)
-        rays += int(s.radiance_rays); shadow += int(s.shadow_rays); paths += int(s.paths)
+        rays += int(s.radiance_rays); shadow += int(s.shadow_rays); paths += int(s.paths); culled += int(s.culled_rays)
         kernel_ms.append(float(s.kernel_ms))
         last_stats = s
         k += n
@@ -312,18 +344,21 @@ def main():
     elapsed = time.perf_counter() - t0
     cdev = dev if (world > 1 and not rehearse) else None
     elapsed = D.max_over_ranks(elapsed, cdev)
-    tot_rays, tot_shadow, tot_paths = D.sum_over_ranks([rays, shadow, paths], cdev)
+    tot_rays, tot_shadow, tot_paths, tot_culled = D.sum_over_ranks([rays, shadow, paths, culled], cdev)
+    if a.variant >= 0:
+        assert int(last_stats.variant) == a.variant, "the kernel variant that ran is not the one requested"
 
     # ---- report ---------------------------------------------------------------------------------------
     if rank == 0:
         all_rays = tot_rays + tot_shadow
         n_launches = max(1, len(kernel_ms))
         vname = L.pt_variant_name(int(last_stats.variant))
-        roof = roofline_block(a, info, world, fuse, kernel_ms, (rays + shadow) / n_launches, a.steps / n_launches,
-                              vname.decode() if vname else "?")
+        vkern = L.pt_variant_kernel(int(last_stats.variant))
+        roof = roofline_block(a, info, world, fuse, kernel_ms, (rays + shadow - culled) / n_launches, (rays + shadow) / n_launches, a.steps / n_launches,
+                              vname.decode() if vname else "?", vkern.decode() if vkern else "", L.pt_kernel_source_hash().decode())
         miss = primary_miss_fraction(p, info)
         out = {
-            "metric": "Mray/s at %s, %d spp, %d bounces (radiance + shadow rays per second)"
+            "metric": "Mray/s at %s, %d spp, %d bounces (radiance + shadow rays per second; camera rays that miss the scene box are radiance segments too and are counted, see config.culled_rays)"
                       % ("1080p" if (a.width, a.height) == (WIDTH, HEIGHT) else "%dx%d" % (a.width, a.height), a.spp * a.steps, a.max_depth),
             "value": all_rays / elapsed / 1e6,
             "unit": "Mray/s",
@@ -341,8 +376,8 @@ def main():
                        "steps_per_kernel_launch": fuse, "kernel_launches": n_launches,
                        "parallelism": "pixel tiles 8x4 over %d GPU(s)%s" % (world, ", RCCL reduce of float4 accumulation" if world > 1 else ""),
                        "rays": int(all_rays), "paths": int(tot_paths), "rays_per_path": all_rays / max(1.0, tot_paths),
-                       "primary_miss_fraction": miss, "rays_entering_scene": int(all_rays - miss * tot_paths),
-                       "Mray_per_s_entering_scene": (all_rays - miss * tot_paths) / elapsed / 1e6,
+                       "primary_miss_fraction": miss, "culled_rays": int(tot_culled), "rays_entering_scene": int(all_rays - tot_culled),
+                       "Mray_per_s_entering_scene": (all_rays - tot_culled) / elapsed / 1e6,
                        "sample_runs_per_pixel": int(last_stats.sample_chunks),
                        "bvh": {"nodes": info.n_nodes, "max_depth": info.max_depth, "stack_entries": info.stack_entries, "build_ms": info.build_ms}},
             "roofline": roof,

@@ -1,0 +1,63 @@
+/*
+ * acgpt_test.h — test hooks and diagnostics of libacgpt_hip.so.
+ *
+ * NOT part of the drop-in boundary (include/acgpt.h): nothing here stands in for a function of the reference's
+ * PathTracerMain.cpp.  The parity tests and the tools under tools/ use these to hold the device functions against golden
+ * vectors and to look inside the scheduler; a binding of the render path never needs them.
+ */
+#ifndef ACGPT_TEST_H
+#define ACGPT_TEST_H
+
+#include "acgpt.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Diagnostic: pure-traversal throughput.  Streams n HOST rays (same 8-float records; tmax < 0 marks an
+ * any-hit ray of length |tmax|) through a persistent kernel that contains nothing but the BVH loop, `repeats`
+ * times, and reports the fastest kernel time.  node_format 0: two-child fp32 tree; 1: four-wide 8-bit tree;
+ * 2: two-child tree with the slab test as one fma per plane (the render kernel's form).
+ * Results: closest rays as pt_trace_closest; any-hit rays give t_out = prim_out = 1 when occluded, 0
+ * otherwise.  counters_out (may be NULL): 5 values of the last repeat — loop iterations summed over waves,
+ * node visits summed over lanes, triangle tests summed over lanes, iterations with a node visit, iterations
+ * with a triangle round.  Not used by the render path.                                                   */
+int pt_bench_traversal(pt_ctx* ctx, const float* rays, size_t n, int repeats, int node_format, float* t_out, uint32_t* prim_out, float* ms_out,
+                       uint64_t* counters_out);
+/* Test hook: evaluates the device functions the render kernel is built from on HOST inputs (n elements), so that
+ * the GPU implementations can be held against golden vectors of the reference's own code directly.
+ *   op 0  tea<4> (cuda/random.h:31-46)            in uint32[n][2]                 out uint32[n]
+ *   op 1  lcg / rnd stream (cuda/random.h:49-67)  in {seed, count}, n = 1         out uint32 states[count], float values[count]
+ *   op 2  make_color (cuda/helpers.h:35-62)       in float[n][3]                  out uchar4[n]
+ *   op 3..8 normalize, reflect, faceforward, lerp, cross, a / s (sutil/vec_math.h)  in float[n][10] = a, b, c, s   out float[n][3]
+ *   op 9  refract (cuda/helpers.h:107-137)        in float[n][7] = i, n, ior      out float[n][4] = r, ok (uint32)
+ *   op 10 StaticWorkDistribution::getSamplePixel (sutil/WorkDistribution.h:59-81)  in int32[n][4] = world, width, rank, sample   out int32[n][2]
+ *   op 11 sinf(x), cosf(x) and the pair sincosf(x) gives (the samplers use the latter)   in float[n]   out float[n][4]
+ * the OptiX-free helpers of pathTracerPrograms.cu, golden vectors from the reference's own text (oracle/_ref):
+ *   op 12 OrthonormalBasis(n).inverse_transform(p) (:54-85)        in float[n][6] = n, p            out float[n][3]
+ *   op 13 safeDivide(float3, float) (:265-284)                      in float[n][4] = a, b            out float[n][3]
+ *   op 14 cosine_sample_hemisphere (:341-353)                       in float[n][2] = eta1, eta2      out float[n][3]
+ *   op 15 uniform_sample_hemisphere (:368-380)                      in float[n][2] = u1, u2          out float[n][3]
+ *   op 16 sampleGGX (:455-476)                                      in float[n][6] = u1, u2, roughness, N   out float[n][3]
+ *   op 17 fresnelSchlickConductor (:494-510)                        in float[n][7] = cosTheta, eta, k       out float[n][3]
+ *   op 18 FrDielectric (:534-559)                                   in float[n][3] = cosThetaI, etaI, etaT  out float[n][1]
+ * and the default kernel's own ray / box test (no reference counterpart: OptiX traverses there), end to end:
+ *   op 19 fp16 slab test: box -> outward fp16 planes, ray -> per-axis multiplier / addend with the rotate flags in the
+ *         multiplier's low bits, entry / exit distance          in float[n][17] = ray o, d, box lo, hi, scene centre, inv_scale
+ *         (a power of two), tmax    out uint32[n][3] = accepted, entry t (float bits), exit t (float bits).  Must accept every
+ *         ray that meets the box shrunk by the builder's pad (tests/test_gpu_golden.py).                                       */
+int pt_selftest(pt_ctx* ctx, int op, const void* in, size_t n, void* out);
+/* Diagnostic: after a launch of a "+ scheduler stats" kernel variant, three 100 MHz stamps per wave (start,
+ * first time it found the work queue empty, end; 0 = wave did not run), HOST output of 3 * max_waves values. */
+int pt_debug_wave_times(pt_ctx* ctx, uint64_t* out, size_t max_waves);
+/* ... and, per work-queue shard (8), the stamp of the first grant past each 1/256 of the shard: HOST output of
+ * 8 * 256 values (0 = never reached by a stamped grant), followed by ONE value: the time all waves together spent
+ * in the shade / regenerate phase, in 10 ns units and its split into queue refill / finished runs / camera-path start (2056 values in all: 2048 + 1 + 3, rest unused). */
+int pt_debug_queue_progress(pt_ctx* ctx, uint64_t* out);
+/* Sorted (morton, triangle) pairs of the last build, HOST outputs of n_tris. */
+int pt_read_morton(pt_ctx* ctx, uint32_t* codes_sorted, uint32_t* prims_sorted);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACGPT_TEST_H */

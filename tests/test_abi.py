@@ -19,8 +19,8 @@ def lib():
     return _native.hip()
 
 
-def header_symbols():
-    text = open(os.path.join(ROOT, "include", "acgpt.h")).read()
+def header_symbols(name="acgpt.h"):
+    text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(pt_[a-z_]+)\s*\(", text)))
 
@@ -31,10 +31,16 @@ def test_exports_every_declared_symbol(lib):
     for s in syms:
         assert hasattr(lib, s), "libacgpt_hip.so does not export %s" % s
     assert sorted(_native.ABI_SYMBOLS) == syms, "the Python binding and the header disagree"
+    # test hooks and diagnostics live in their own header: a maintainer binding the render path does not see them
+    hooks = header_symbols("acgpt_test.h")
+    assert sorted(_native.TEST_SYMBOLS) == hooks and not set(hooks) & set(syms)
+    for s in hooks:
+        assert hasattr(lib, s), "libacgpt_hip.so does not export %s" % s
     out = subprocess.run(["nm", "-D", "--defined-only", _native.hip_library_path()], capture_output=True, text=True, check=True).stdout
     exported = set(re.findall(r" T (pt_[a-z_]+)", out))
-    assert exported == set(syms)
-    assert lib.pt_abi_version() == 1
+    assert exported == set(syms) | set(hooks)
+    assert lib.pt_abi_version() == 2 == _native.ABI_VERSION
+    assert C.sizeof(_native.Stats) == 88 and C.sizeof(_native.BvhInfo) == 80
 
 
 def test_pod_layouts_match_the_reference():

@@ -7,6 +7,9 @@
     path): accumulation and framebuffer must equal the one-rank run bit for bit at equal sample runs.
 (b) an RCCL collective on a device tensor executes on this hardware: world 1, backend "nccl", the same
     reduce / all_reduce calls distributed.py issues (tools/rccl_selfcheck.py).
+(c) the same split behind the C ABI (pt_create_multi, what a C++ caller of the drop-in uses): acgpt_main --gpus N with every
+    rank on the one GPU and a sum kernel standing in for RCCL (a rehearsal, labelled so in include/acgpt.h), and the group
+    context over ONE device, whose ncclReduce runs in-process through librccl with one rank; accumulation save / restore.
 Every child is a fresh process started from pytest (nothing that touched the GPU is re-exec'ed).  A real 2..8-GPU
 RCCL run is the driver's to make; DESIGN.md §6 keeps the "unmeasured on 8 GPUs" label until it has."""
 import json
@@ -70,3 +73,47 @@ def test_two_ranks_equal_one_rank(built, tmp_path):
 def test_rccl_collective_runs_on_this_gpu(built):
     r = _run([sys.executable, os.path.join("tools", "rccl_selfcheck.py")], {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
     assert "NCCL_OK" in r.stdout, r.stdout + r.stderr
+
+
+def _app(tmp_path, tag, extra, env=None, frames=5):
+    """acgpt_main (the C++ mirror of PathTracerMain.cpp) on a 328 x 204 image, 16 spp per launch; returns (ppm bytes, accumulation dump bytes, stdout)."""
+    exe = os.path.join(ROOT, "acgpathtracing_amd", "acgpt_main")
+    if not os.path.exists(exe):
+        from acgpathtracing_amd import _build
+        _build.build_hip(); _build.build_main()
+    out, acc = str(tmp_path / (tag + ".ppm")), str(tmp_path / (tag + ".acc"))
+    cmd = [exe, "--obj", os.path.join(ROOT, "acgpathtracing_amd", "scenes", "cornell_box.obj"), "--width", "328", "--height", "204",
+           "--spp-per-launch", "16", "--frames", str(frames), "--fuse-frames", "4", "--max-depth", "6", "--direct-lighting", "--importance-sampling",
+           "--sample-chunks", "4", "--out", out, "--save-accum", acc] + extra
+    r = _run(cmd, env or {})
+    return open(out, "rb").read(), open(acc, "rb").read(), r.stdout
+
+
+def test_group_context_behind_the_c_abi(built, tmp_path):
+    """pt_create_multi: N devices behind the one context a caller of the drop-in holds."""
+    reh = {"ACGPT_REHEARSE_SAME_GPU": "1"}
+    one = _app(tmp_path, "one", [])
+    assert len(one[1]) == 20 + 328 * 204 * 16 and "Total Samples 80" in one[2]
+    # the group over one device: private buffer -> ncclReduce (librccl in-process, one rank) -> caller's buffer -> make_color
+    solo = _app(tmp_path, "solo", ["--multi"])
+    assert "Devices: 1" in solo[2]
+    assert solo[:2] == one[:2], "the one-device group (RCCL reduce with one rank) differs from pt_create"
+    # two and three ranks on the one GPU (rehearsal: a sum kernel stands in for RCCL); 3 exercises the per-strip rotation
+    for n in (2, 3):
+        grp = _app(tmp_path, "grp%d" % n, ["--gpus", str(n)], reh)
+        assert "Devices: %d" % n in grp[2]
+        assert grp[:2] == one[:2], "--gpus %d differs from one device" % n
+    # without the rehearsal switch a device listed twice is refused
+    import ctypes as C
+    from acgpathtracing_amd import _native
+    L = _native.hip()
+    ctx = C.c_void_p()
+    assert "ACGPT_REHEARSE_SAME_GPU" not in os.environ
+    assert L.pt_create_multi(C.byref(ctx), (C.c_int * 2)(0, 0), 2) != 0 and b"twice" in L.pt_last_error(None)
+    # save / restore of the progressive state: 3 frames, then 2 more in a new process == 5 frames straight; on one device
+    # and on a group (whose ranks take their own pixels of the restored buffer)
+    for tag, extra, env in (("r1", [], {}), ("r2", ["--gpus", "2"], reh)):
+        first = _app(tmp_path, tag + "a", extra, env, frames=3)
+        rest = _app(tmp_path, tag + "b", extra + ["--restore-accum", str(tmp_path / (tag + "a.acc"))], env, frames=2)
+        assert "Accumulation restored: 3 frames" in rest[2]
+        assert first[1] != one[1] and rest[:2] == one[:2], tag

@@ -8,6 +8,8 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
 
 def main():
     d = sys.argv[1]
@@ -17,11 +19,16 @@ def main():
         out["command"] = sys.argv[3]
     if len(sys.argv) > 4:
         out["steps_per_kernel_launch"] = int(sys.argv[4])
+    try:        # what the profile was taken on: bench.py quotes it only for a library built from the same kernel sources
+        from acgpathtracing_amd import _build
+        out["kernel_source_hash"] = _build.kernel_source_hash()
+    except Exception as e:
+        out["kernel_source_hash"] = "unknown (%s)" % e
     st = os.path.join(d, "trace", "trace_kernel_stats.csv")
     if os.path.exists(st):
         for r in csv.DictReader(open(st)):
             if kern in r["Name"]:
-                out["kernel_stats"] = {"name": r["Name"][:80], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
+                out["kernel_stats"] = {"name": r["Name"], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
                                        "min_ms": float(r["MinNs"]) / 1e6, "max_ms": float(r["MaxNs"]) / 1e6, "pct": float(r["Percentage"])}
                 break
     pmc = {}
