@@ -820,10 +820,12 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
     { Range range("acgpt: render megakernel (launch_batch)"); CK(c, ptd::launch_render(variant, a, grid, c->stream)); }
     CK(c, hipEventRecord(c->ev1, c->stream));
     { Range range("acgpt: k_finalize"); CK(c, ptd::launch_finalize(a, c->stream)); }
-    unsigned long long h[8], h_culled = 0;
+    unsigned long long h[8], h_tail[2] = {0, 0};
     CK(c, hipMemcpyAsync(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-    CK(c, hipMemcpyAsync(&h_culled, c->d_counters + ptd::kCulledCounter, sizeof(h_culled), hipMemcpyDeviceToHost, c->stream));
+    CK(c, hipMemcpyAsync(h_tail, c->d_counters + ptd::kCulledCounter, sizeof(h_tail), hipMemcpyDeviceToHost, c->stream));
     CK(c, hipStreamSynchronize(c->stream));            // CUDA_SYNC_CHECK, PathTracerMain.cpp:209
+    const unsigned long long h_culled = h_tail[0];
+    if (h_tail[1] != 0) return fail(c, "pt_launch: the render kernel gave up (" + std::to_string(h_tail[1]) + " workgroups: scheduling error or watchdog); the image is incomplete");
     float ms = 0.0f;
     CK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->stats.radiance_rays = h[0];

@@ -11,6 +11,7 @@ constexpr uint32_t kMaxTimedWaves = 16384;   // stats variants stamp start / que
 // layout of RenderArgs::counters (64-bit words): [0, 8) ray / path / scheduler counters, [8, 8 + 3 * kMaxTimedWaves) wave stamps,
 // then 2056 words of queue progress and phase times (stats variants), then kTailCounters more launch counters
 constexpr uint32_t kCulledCounter = 8u + 3u * kMaxTimedWaves + 2056u;   // camera rays ended by the scene-box cull (they are part of counters[0] and [2] too)
+constexpr uint32_t kAbortCounter = kCulledCounter + 1u;                 // workgroups of a wavefront kernel that gave up (scheduling error or watchdog): the launch fails
 constexpr uint32_t kTailCounters = 8u;
 constexpr uint32_t kCounterWords = kCulledCounter + kTailCounters;
 // Variant indices of the product library (render_megakernel.hip kVariants).  pt_set_scene picks one per scene unless
@@ -22,6 +23,7 @@ constexpr uint32_t kCounterWords = kCulledCounter + kTailCounters;
 // rounds at 8 lanes above kLargeSceneTris.
 constexpr int kVariantSync = 0, kVariantF32 = 1, kVariantF32Stats = 2, kVariantF32Large = 3, kVariantFastMath = 4;
 constexpr int kVariantF16 = 5, kVariantF16Stats = 6, kVariantF16W5 = 7, kVariantLights = 8, kVariantF16W5Deep = 9;
+constexpr int kVariantWf16 = 10, kVariantWf10 = 11;      // workgroup-level wavefront kernels (render_wavefront.hip)
 constexpr int kDefaultVariant = kVariantF16W5;
 constexpr uint32_t kLargeSceneTris = 100000;
 constexpr float kHalfAreaLimit = 1.5f, kHalfInflationLimit = 3.0f;
