@@ -54,12 +54,13 @@ def kernel_source_hash():
 
 def build_hip(force=False, verbose=False, experiments=False):
     """experiments=True builds libacgpt_hip_exp.so: the same library plus every kernel variant that was measured and
-    not adopted (-DACGPT_EXPERIMENTS; tools/sweep_variants.py loads it via ACGPT_EXPERIMENTS=1).  Never the product."""
+    not adopted (-DACGPT_EXPERIMENTS; tools/sweep_variants.py loads it via ACGPT_EXPERIMENTS=1).  Never the product.
+    By default only the current round's experiments are compiled in; ACGPT_EXPERIMENTS_ALL=1 adds the ~70 of earlier rounds."""
     out = os.path.join(PKG, "libacgpt_hip_exp.so" if experiments else "libacgpt_hip.so")
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     deps = srcs + [os.path.join(CSRC, h) for h in HIP_HEADERS] + [os.path.join(ROOT, "include", "acgpt.h"), os.path.join(ROOT, "include", "acgpt_test.h")]
     if force or _stale(out, deps):
-        cmd = [_hipcc()] + HIP_FLAGS + (["-DACGPT_EXPERIMENTS"] if experiments else []) + \
+        cmd = [_hipcc()] + HIP_FLAGS + (["-DACGPT_EXPERIMENTS=%d" % (2 if os.environ.get("ACGPT_EXPERIMENTS_ALL") == "1" else 1)] if experiments else []) + \
               ['-DACGPT_KERNEL_SRC_HASH="%s"' % kernel_source_hash(), "-o", out] + srcs + ["-ldl", "-pthread"]
         if verbose:
             print(" ".join(cmd))

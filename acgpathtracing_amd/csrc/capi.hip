@@ -992,6 +992,14 @@ PT_API int pt_debug_queue_progress(pt_ctx* c, uint64_t* out)
     return 0;
 }
 
+PT_API int pt_debug_wf(pt_ctx* c, uint64_t* out)
+{
+    if (!c || !out) return fail(c, "pt_debug_wf: null argument");
+    CK(c, hipSetDevice(c->device));
+    CK(c, hipMemcpy(out, c->d_counters + ptd::kWfDiag, 17 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 PT_API int pt_read_morton(pt_ctx* c, uint32_t* codes_sorted, uint32_t* prims_sorted)
 {
     if (!c || !codes_sorted || !prims_sorted) return fail(c, "pt_read_morton: null argument");

@@ -1060,7 +1060,25 @@ static const VariantDesc kVariants[] = {
     {PW(44, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "pw K44 L16 fp16 sign-rotated nodes, five waves per SIMD for deep trees: 28 stack entries per lane in LDS, deeper ones in global memory", 28, PWN(44, 16, 9, 256, 5, false, 0, 5, 2, false, 28)},
     {nullptr, 0, 9, nullptr, 0, nullptr, 0},      // kVariantWf16: filled from render_wavefront.hip's table (variant_desc)
     {nullptr, 0, 9, nullptr, 0, nullptr, 1},      // kVariantWf10
+    {nullptr, 0, 9, nullptr, 0, nullptr, 2},
+    {nullptr, 0, 9, nullptr, 0, nullptr, 3},
+    {nullptr, 0, 9, nullptr, 0, nullptr, 4},
 #ifdef ACGPT_EXPERIMENTS
+    // round 3: the shape of a trip through the BVH loop (visits per trip, triangle tests per round, lanes a round waits for)
+    {PW(44, 1, 9, 256, 5, false, 0, 2, 1, false, 0), 256, 9, "r3 K44 L1 V2 T1 (visit, visit, test: a lane never waits more than one slot)"},
+    {PW(44, 1, 9, 256, 5, false, 0, 3, 1, false, 0), 256, 9, "r3 K44 L1 V3 T1"},
+    {PW(44, 8, 9, 256, 5, false, 0, 2, 1, false, 0), 256, 9, "r3 K44 L8 V2 T1"},
+    {PW(44, 8, 9, 256, 5, false, 0, 3, 1, false, 0), 256, 9, "r3 K44 L8 V3 T1"},
+    {PW(44, 1, 9, 256, 5, false, 0, 2, 2, false, 0), 256, 9, "r3 K44 L1 V2 T2"},
+    {PW(44, 8, 9, 256, 5, false, 0, 3, 2, false, 0), 256, 9, "r3 K44 L8 V3 T2"},
+    {PW(44, 1, 9, 256, 5, false, 0, 1, 1, false, 0), 256, 9, "r3 K44 L1 V1 T1"},
+    {PW(44, 8, 9, 256, 5, false, 0, 4, 2, false, 0), 256, 9, "r3 K44 L8 V4 T2"},
+    {PW(48, 1, 9, 256, 5, false, 0, 2, 1, false, 0), 256, 9, "r3 K48 L1 V2 T1"},
+    {PW(40, 1, 9, 256, 5, false, 0, 2, 1, false, 0), 256, 9, "r3 K40 L1 V2 T1"},
+    {PW(44, 4, 9, 256, 5, false, 0, 2, 1, false, 0), 256, 9, "r3 K44 L4 V2 T1"},
+    {PW(44, 24, 9, 256, 5, false, 0, 5, 2, false, 0), 256, 9, "r3 K44 L24 V5 T2"},
+    {PW(44, 32, 9, 256, 5, false, 0, 5, 2, false, 0), 256, 9, "r3 K44 L32 V5 T2"},
+#if ACGPT_EXPERIMENTS >= 2
     {k_render_pw<40, 8, 0, 256, 4, false, 0, 1>, 256, 0, "pw K40 L8 fp32 w4, register stack top"},
     {k_render_pw<48, 8, 0, 256, 4, false>, 256, 0, "pw K48 L8 fp32 w4, LDS-only stack"},
     {k_render_pw<48, 8, 0, 256, 5, false, 0, 1>, 256, 0, "pw K48 L8 fp32 w5 (register-capped, spills)"},
@@ -1136,6 +1154,7 @@ static const VariantDesc kVariants[] = {
     {k_render_pw<44, 16, 9, 256, 5, false, 0, 5, 3>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) V5 T3 w5"},
     {k_render_pw<44, 16, 7, 256, 5, false, 0, 3, 2, false, 28>, 256, 7, "pw K44 L16 fp16 min / max V3 T2 w5, 28 stack entries in LDS", 28},
     {k_render_pw<44, 16, 7, 256, 5, false, 0, 5, 2>, 256, 7, "pw K44 L16 fp16 min / max V5 T2 w5"},
+#endif
 #endif
 };
 int render_variant_count() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }

@@ -242,7 +242,7 @@ __device__ __forceinline__ void wf_refill(const RenderArgs& A, QueueState& q, ui
 // stack in LDS (deeper ones in global memory); a trace wave exchanges records when FETCH_K lanes are idle; triangle rounds at
 // LEAF_K lanes; VISITS node visits per trip through the loop control.  fp16 nodes (HNode, the slab test of NODE_FMT 9).
 // =================================================================================================================================
-template <int NT, int NS, int POOL, int STACK_CAP, int FETCH_K, int LEAF_K, int VISITS, int MINB>
+template <int NT, int NS, int POOL, int STACK_CAP, int FETCH_K, int LEAF_K, int VISITS, int MINB, bool DIAG>
 __global__ void __launch_bounds__((NT + NS) * 64, MINB)
 k_render_wf(const RenderArgsBox B)
 {
@@ -279,14 +279,13 @@ k_render_wf(const RenderArgsBox B)
     if (threadIdx.x < 64u) { ctl->grp_pxy[threadIdx.x] = 0xFFFFFFFFu; ctl->grp_seed[threadIdx.x] = 0u; }
     __syncthreads();
 
-    WgBook book; book.tick = tick; book.free16 = free16; book.gslot = ctl->gslot;
-    float* const scratch = A.wave_scratch + 3u * (size_t)(blockIdx.x * (THREADS / 64)) * ((size_t)kRenderFoldSlots << A.chunk_shift);
-    DeviceScene sc = A.scene;
-    const int root = sc.n_tris ? 0 : kSentinel;
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
     constexpr unsigned long long kWatchdogTicks = 2000000000ull;       // 20 s at 100 MHz: a launch takes 0.1 ... 1 s
     unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0, n_culled = 0;
     unsigned long long n_steps = 0, n_lane_steps = 0, n_rounds = 0, n_lane_rounds = 0;
+    // diagnostics (10 ns ticks and counts, summed over the waves of the grid): trace waves: total, idle; shade waves: total, idle,
+    // deal / hit / accounting rounds: time, rounds, records
+    unsigned long long d_total = 0, d_idle = 0, d_deal = 0, d_hit = 0, d_acct = 0, c_deal = 0, c_hit = 0, c_acct = 0, l_deal = 0, l_hit = 0, l_acct = 0;
     bool trouble = false;
     const auto late = [&]() -> const RenderArgs& { return B.a[opaque_zero()]; };
     const auto poll_stop = [&]() -> bool {
@@ -298,6 +297,9 @@ k_render_wf(const RenderArgsBox B)
     if (wave >= (uint32_t)NS) {
         // ======================================= TRACE wave ==================================================================
         const uint32_t tw = wave - (uint32_t)NS;
+        const HNode* const hnodes = A.scene.hnodes;
+        const TriRecord* const tris = A.scene.tris;
+        const int root = A.scene.n_tris ? 0 : kSentinel;
         LaneStack st;
         st.base = stacks + tw * (lds_entries * 64u) + lane;
         uint32_t* const ovf = A.stack_entries > lds_entries
@@ -320,6 +322,7 @@ k_render_wf(const RenderArgsBox B)
             const int n_idle = 64 - popc(am);
             if ((n_idle >= FETCH_K && cooldown <= 0) || am == 0ull) {
                 // ---- exchange: finished records out, ready records in -------------------------------------------------------
+                const unsigned long long t_ex = DIAG ? __builtin_amdgcn_s_memrealtime() : 0ull;
                 const bool idle = !act;
                 const bool fin = idle && has_rec;
                 uint32_t s = ring_pop<POOL>(&ctl->q[QT], cells + QT * POOL, idle, lane, below, trouble);
@@ -361,11 +364,12 @@ k_render_wf(const RenderArgsBox B)
                 }
                 const unsigned long long now_active = vote(node != kSentinel);
                 cooldown = vote(swap_in) != 0ull ? 0 : 4;                  // nothing came: look again a few trips later
+                if (DIAG) { d_deal += __builtin_amdgcn_s_memrealtime() - t_ex; c_deal += 1; l_deal += (unsigned long long)popc(vote(swap_in)); }
                 if (now_active == 0ull) {
                     if (vote(has_rec) == 0ull && lds_load(&ctl->done) != 0u) break;
                     if (vote(trouble) != 0ull) { if (lane == 0) __hip_atomic_store(&ctl->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
                     if (poll_stop()) break;
-                    __builtin_amdgcn_s_sleep(8);
+                    if (DIAG) { const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_sleep(8); d_idle += __builtin_amdgcn_s_memrealtime() - t0; } else __builtin_amdgcn_s_sleep(8);
                     continue;
                 }
             }
@@ -376,7 +380,7 @@ k_render_wf(const RenderArgsBox B)
             for (int visit = 0; visit < VISITS; visit++)
             if ((uint32_t)node < (uint32_t)kSentinel) {
                 float n0, f0, n1, f1; int c0, c1;
-                const uint4* np = (const uint4*)((const char*)sc.hnodes + (size_t)((uint32_t)node << 5));
+                const uint4* np = (const uint4*)((const char*)hnodes + (size_t)((uint32_t)node << 5));
                 const uint4 qa = np[0], qb = np[1];
                 c0 = (int)qa.w; c1 = (int)qb.w;
                 slab_h9(qa.x, qa.y, qa.z, rinv, gro, rtmin, n0, f0);
@@ -403,7 +407,7 @@ k_render_wf(const RenderArgsBox B)
                 for (int leaf = 0; leaf < 2; leaf++)
                 if (node < 0) {
                     const int slot = ~node;
-                    const TriRecord* tp = (const TriRecord*)((const char*)sc.tris + (size_t)((uint32_t)slot * 48u));
+                    const TriRecord* tp = (const TriRecord*)((const char*)tris + (size_t)((uint32_t)slot * 48u));
                     const float4 r0 = tp->r0, r1 = tp->r1, r2 = tp->r2;
                     float t;
                     const bool ok = tri_test_lazy(ro, rd, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, r2.x), rtmin, rtmax, t);
@@ -421,6 +425,7 @@ k_render_wf(const RenderArgsBox B)
         }
     } else {
         // ======================================= SHADE wave ==================================================================
+        WgBook book; book.tick = tick; book.free16 = free16; book.gslot = ctl->gslot;
         constexpr int kLowWater = POOL / 4;            // ready rays below which the trace waves are about to run dry: shade whatever is there
         for (;;) {
             if (lds_load(&ctl->done) != 0u) break;
@@ -443,10 +448,13 @@ k_render_wf(const RenderArgsBox B)
                 else if (nm >= thr) choice = 2;
                 else if (nh >= thr) choice = 1;
             }
-            if (choice < 0) { __builtin_amdgcn_s_sleep(4); continue; }
+            if (choice < 0) { if (DIAG) { const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_s_sleep(4); d_idle += __builtin_amdgcn_s_memrealtime() - t0; } else __builtin_amdgcn_s_sleep(4); continue; }
+            const unsigned long long t_round = DIAG ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
             if (choice == 0) {
                 // ---------------------------------- DEAL round (lock held) ----------------------------------------------------
+                const RenderArgs& Ad = late();          // the launch constants of the deal are read here, not held across the kernel
+                float* const scratch = Ad.wave_scratch + 3u * (size_t)(blockIdx.x * (THREADS / 64)) * ((size_t)kRenderFoldSlots << Ad.chunk_shift);
                 QueueState q;
                 q.shard = ctl->shard; q.shards_left = ctl->shards_left; q.res_first = ctl->res_first; q.res_count = ctl->res_count;
                 q.grant_g0 = ctl->grant_g0; q.free_top = ctl->free_top; q.grp_pxy = ctl->grp_pxy[lane]; q.grp_seed = ctl->grp_seed[lane];
@@ -471,10 +479,10 @@ k_render_wf(const RenderArgsBox B)
                 for (int pass = 0; pass < 8; pass++) {
                     const int n_fin = popc(vote(finished));
                     n_pixels += (unsigned long long)n_fin; live_delta -= n_fin;
-                    wf_finish_runs(A, q, below, lp, finished, book, scratch);
+                    wf_finish_runs(Ad, q, below, lp, finished, book, scratch);
                     finished = false;
                     const unsigned long long before = vote(lp.alive);
-                    wf_refill(A, q, lane, below, lp, lcg_skip, book);
+                    wf_refill(Ad, q, lane, below, lp, lcg_skip, book);
                     live_delta += popc(vote(lp.alive) & ~before);
                     // camera path start (:727-745) with the scene-box cull, as in k_render_pw
                     uint32_t my_culled = 0u;
@@ -506,7 +514,7 @@ k_render_wf(const RenderArgsBox B)
                 {   // a run that ran out of samples in the last pass's cull still has to be folded
                     const int n_fin = popc(vote(finished));
                     n_pixels += (unsigned long long)n_fin; live_delta -= n_fin;
-                    wf_finish_runs(A, q, below, lp, finished, book, scratch);
+                    wf_finish_runs(Ad, q, below, lp, finished, book, scratch);
                 }
                 const bool armed = have && lp.alive;
                 n_radiance += (unsigned long long)popc(vote(armed));
@@ -539,6 +547,7 @@ k_render_wf(const RenderArgsBox B)
                 ring_push<POOL>(&ctl->q[QT], cells + QT * POOL, armed, slot, lane, below);
                 ring_push<POOL>(&ctl->q[QF], cells + QF * POOL, have && !armed, slot, lane, below);
                 if (lane == 0) __hip_atomic_store(&ctl->deal_lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (DIAG) { d_deal += __builtin_amdgcn_s_memrealtime() - t_round; c_deal += 1; l_deal += (unsigned long long)popc(vote(have)); }
                 continue;
             }
 
@@ -584,7 +593,7 @@ k_render_wf(const RenderArgsBox B)
                     f3 P, L; float Ldist;
                     f3 emission = mk(0.0f);
                     if (hit >= 0) {
-                        want_shadow = shade_hit<false, false>(sc, late, ro, rd, tmax, hit, depth, pseed, att, emission, pd, P, L, Ldist);
+                        want_shadow = shade_hit<false, false>(late().scene, late, ro, rd, tmax, hit, depth, pseed, att, emission, pd, P, L, Ldist);
                     } else {                                              // __miss__ms :833-847
                         pd.radiance = mk(0.0f); pd.weight = 0.0f; pd.done = true;
                     }
@@ -608,7 +617,7 @@ k_render_wf(const RenderArgsBox B)
                 result += pd.radiance * att;
                 const float p = dot(att, mk(0.30f, 0.59f, 0.11f));
                 const bool rr = rnd(pseed) > p;
-                end = pd.done || rr || (uint32_t)depth >= A.maxDepth;
+                end = pd.done || rr || (uint32_t)depth >= late().maxDepth;
                 if (!end) {
                     att = mk(safe_div(att.x, p), safe_div(att.y, p), safe_div(att.z, p));
                     ro = pd.nxt_org; rd = pd.nxt_dir;
@@ -669,21 +678,33 @@ k_render_wf(const RenderArgsBox B)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             ring_push<POOL>(&ctl->q[QT], cells + QT * POOL, have && !finished, slot, lane, below);
             ring_push<POOL>(&ctl->q[QR], cells + QR * POOL, have && finished, slot, lane, below);
+            if (DIAG && choice == 1) { d_hit += __builtin_amdgcn_s_memrealtime() - t_round; c_hit += 1; l_hit += (unsigned long long)popc(vote(have)); }
+            else if (DIAG) { d_acct += __builtin_amdgcn_s_memrealtime() - t_round; c_acct += 1; l_acct += (unsigned long long)popc(vote(have)); }
         }
     }
+    if (DIAG) d_total = __builtin_amdgcn_s_memrealtime() - t_begin;
 
     if (lane == 0) {
-        atomicAdd(&A.counters[0], n_radiance);
-        atomicAdd(&A.counters[1], n_shadow);
-        atomicAdd(&A.counters[2], n_paths);
-        atomicAdd(&A.counters[3], n_pixels);
-        atomicAdd(&A.counters[4], n_steps);
-        atomicAdd(&A.counters[5], n_lane_steps);
-        atomicAdd(&A.counters[6], n_rounds);
-        atomicAdd(&A.counters[7], n_lane_rounds);
-        if (n_culled) atomicAdd(&A.counters[kCulledCounter], n_culled);
+        atomicAdd(&late().counters[0], n_radiance);
+        atomicAdd(&late().counters[1], n_shadow);
+        atomicAdd(&late().counters[2], n_paths);
+        atomicAdd(&late().counters[3], n_pixels);
+        atomicAdd(&late().counters[4], n_steps);
+        atomicAdd(&late().counters[5], n_lane_steps);
+        atomicAdd(&late().counters[6], n_rounds);
+        atomicAdd(&late().counters[7], n_lane_rounds);
+        if (n_culled) atomicAdd(&late().counters[kCulledCounter], n_culled);
+        unsigned long long* dg = late().counters + kWfDiag;
+        if (!DIAG) {}
+        else if (wave >= (uint32_t)NS) { atomicAdd(&dg[0], d_total); atomicAdd(&dg[1], d_idle); atomicAdd(&dg[13], d_deal); atomicAdd(&dg[14], c_deal); atomicAdd(&dg[15], l_deal); atomicAdd(&dg[16], n_steps); }
+        else {
+            atomicAdd(&dg[2], d_total); atomicAdd(&dg[3], d_idle);
+            atomicAdd(&dg[4], d_deal); atomicAdd(&dg[5], c_deal); atomicAdd(&dg[6], l_deal);
+            atomicAdd(&dg[7], d_hit); atomicAdd(&dg[8], c_hit); atomicAdd(&dg[9], l_hit);
+            atomicAdd(&dg[10], d_acct); atomicAdd(&dg[11], c_acct); atomicAdd(&dg[12], l_acct);
+        }
         const uint32_t ab = lds_load(&ctl->abort_flag);
-        if (ab != 0u) atomicAdd(&A.counters[kAbortCounter], 1ull);         // pt_launch fails: the image is not complete
+        if (ab != 0u) atomicAdd(&late().counters[kAbortCounter], 1ull);         // pt_launch fails: the image is not complete
     }
 }
 
@@ -691,8 +712,11 @@ k_render_wf(const RenderArgsBox B)
 #define WF(...) k_render_wf<__VA_ARGS__>
 #define WFN(...) "k_render_wf<" #__VA_ARGS__ ">"
 static const WfDesc kWfVariants[] = {
-    {WF(12, 4, 512, 16, 16, 16, 5, 1), 12, 4, 512, 16, "wavefront: 12 trace + 4 shade waves per workgroup, 512 record slots in LDS, fp16 nodes, one workgroup per CU", WFN(12, 4, 512, 16, 16, 16, 5, 1)},
-    {WF(8, 2, 256, 16, 16, 16, 5, 2), 8, 2, 256, 16, "wavefront: 8 trace + 2 shade waves per workgroup, 256 record slots, fp16 nodes, two workgroups per CU (five waves per SIMD)", WFN(8, 2, 256, 16, 16, 16, 5, 2)},
+    {WF(12, 4, 512, 16, 16, 16, 5, 1, false), 12, 4, 512, 16, "wavefront: 12 trace + 4 shade waves per workgroup, 512 record slots in LDS, fp16 nodes, one workgroup per CU", WFN(12, 4, 512, 16, 16, 16, 5, 1, false)},
+    {WF(8, 2, 256, 16, 16, 16, 5, 2, false), 8, 2, 256, 16, "wavefront: 8 trace + 2 shade waves per workgroup, 256 record slots, fp16 nodes, two workgroups per CU (five waves per SIMD)", WFN(8, 2, 256, 16, 16, 16, 5, 2, false)},
+    {WF(12, 4, 512, 16, 16, 16, 5, 1, true), 12, 4, 512, 16, "wavefront 12 + 4 with per-role time stamps (pt_debug_wf)", WFN(12, 4, 512, 16, 16, 16, 5, 1, true)},
+    {WF(8, 8, 512, 16, 16, 16, 5, 1, true), 8, 8, 512, 16, "wavefront 8 + 8 with per-role time stamps", WFN(8, 8, 512, 16, 16, 16, 5, 1, true)},
+    {WF(10, 6, 512, 16, 16, 16, 5, 1, true), 10, 6, 512, 16, "wavefront 10 + 6 with per-role time stamps", WFN(10, 6, 512, 16, 16, 16, 5, 1, true)},
 };
 int wf_variant_count() { return (int)(sizeof(kWfVariants) / sizeof(kWfVariants[0])); }
 const WfDesc* wf_variant(int i) { return (i >= 0 && i < wf_variant_count()) ? &kWfVariants[i] : nullptr; }

@@ -22,6 +22,6 @@ for PMC in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
   timeout -k 10 400 rocprofv3 --pmc $PMC --output-format csv -d $OUT/pmc$i -o pmc -- python3 $REPO/bench.py $ARGS > $OUT/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; tail -3 $OUT/pmc$i.log; }
 done
 STEPS_PER_LAUNCH=${STEPS_PER_LAUNCH:-8}
-python3 $REPO/tools/summarize_prof.py $OUT k_render_pw "python bench.py $ARGS" $STEPS_PER_LAUNCH > $OUT/summary.json
+python3 $REPO/tools/summarize_prof.py $OUT ${KERNEL_FILTER:-k_render_pw} "python bench.py $ARGS" $STEPS_PER_LAUNCH > $OUT/summary.json
 cp $OUT/trace/trace_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 head -c 1500 $OUT/summary.json

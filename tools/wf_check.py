@@ -52,6 +52,19 @@ for chunks in chunk_list:
             line += "  bits %s counters %s" % ("SAME" if same else "DIFFER (%d pixels, max abs %.3e)" % (int(np.any(acc != ref[0], axis=-1).sum()), float(np.abs(acc - ref[0]).max())), "same" if cnt == ref[1] else "DIFFER")
             ok = ok and same and cnt == ref[1]
         print(line, flush=True)
+        if st.variant >= 10:
+            d = (C.c_uint64 * 17)()
+            L.pt_debug_wf(state.context, d)
+            d = [int(x) for x in d]
+            tt, ti, stt, si = d[0], d[1], d[2], d[3]
+            print("      trace waves idle %.1f %% | shade waves idle %.1f %%, deal %.1f %% (%d rounds, %.1f rec, %.2f us), hits %.1f %% (%d rounds, %.1f rec, %.2f us), accounting %.1f %% (%d rounds, %.1f rec, %.2f us)"
+                  % (100.0 * ti / max(1, tt), 100.0 * si / max(1, stt),
+                     100.0 * d[4] / max(1, stt), d[5], d[6] / max(1, d[5]), d[4] / max(1, d[5]) / 100.0,
+                     100.0 * d[7] / max(1, stt), d[8], d[9] / max(1, d[8]), d[7] / max(1, d[8]) / 100.0,
+                     100.0 * d[10] / max(1, stt), d[11], d[12] / max(1, d[11]), d[10] / max(1, d[11]) / 100.0), flush=True)
+            if d[14]:
+                print("      trace waves: %.1f %% of their time in exchanges (%d exchanges, %.1f records in, %.2f us each); %d trips, %.2f us per trip without the exchanges, %.2f trips per exchange"
+                      % (100.0 * d[13] / max(1, tt), d[14], d[15] / d[14], d[13] / d[14] / 100.0, d[16], (tt - d[13] - ti) / max(1, d[16]) / 100.0, d[16] / d[14]), flush=True)
 pt.CleanAllTheThings(state)
 print("WF_CHECK", "OK" if ok else "FAILED")
 sys.exit(0 if ok else 1)
