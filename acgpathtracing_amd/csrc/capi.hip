@@ -294,9 +294,10 @@ static int pick_variant(const pt_ctx* c)
     const bool half_ok = c->bvh.half_area_ratio <= ptd::kHalfAreaLimit && c->bvh.half_box_inflation <= ptd::kHalfInflationLimit;
     const bool large = c->bvh.n_tris > ptd::kLargeSceneTris;
     if (!half_ok) return large ? ptd::kVariantF32Large : ptd::kVariantF32;
+    if (c->bvh.n_tris > ptd::kWindowSceneTris) return ptd::kVariantF16W5Deep;     // long rays: earlier shade rounds, windowed stack
     int w5_blocks = 0;      // do five workgroups of the five-wave kernel fit a CU with this tree's stack depth?
     if (ptd::render_occupancy(ptd::kVariantF16W5, c->stack_entries, c->bvh.n_nodes, &w5_blocks) == hipSuccess && w5_blocks >= 5) return ptd::kVariantF16W5;
-    return ptd::kVariantF16W5Deep;      // deep tree: 28 stack entries per lane in LDS, the rest in global memory (1 % ahead of four waves on 1.31 M triangles)
+    return ptd::kVariantF16W5Deep;      // small scene, deep tree: the windowed stack keeps five workgroups on a CU
 }
 
 // dwords per lane: one push per internal node on a root-to-leaf path at most (two-child tree), or one
@@ -802,9 +803,10 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
         a.wave_scratch = c->d_wave_scratch;
     }
     {   // kernels whose LDS stack is capped keep deeper entries here
-        const uint32_t cap = (uint32_t)ptd::render_variant_stack_cap(variant);
+        const int cap_signed = ptd::render_variant_stack_cap(variant);      // > 0: entries in LDS, the rest here; < 0: a sliding window of that many, every slot has a home here
+        const uint32_t cap = (uint32_t)(cap_signed < 0 ? -cap_signed : cap_signed);
         if (cap > 0u && c->stack_entries > cap) {
-            const size_t need = (size_t)grid * wpb * 64u * (c->stack_entries - cap) * sizeof(uint32_t);
+            const size_t need = (size_t)grid * wpb * 64u * (cap_signed < 0 ? c->stack_entries : c->stack_entries - cap) * sizeof(uint32_t);
             if (need > c->stack_ovf_bytes) {
                 CK(c, hipStreamSynchronize(c->stream));
                 if (c->d_stack_ovf) { (void)hipFree(c->d_stack_ovf); c->d_stack_ovf = nullptr; c->stack_ovf_bytes = 0; }

@@ -19,14 +19,16 @@ constexpr uint32_t kCounterWords = kCulledCounter + kTailCounters;
 // pt_set_tuning named one.  fp16 nodes unless the scene has geometry finer than their planes: the mean inflation of a child
 // box by the outward fp16 rounding stays below kHalfInflationLimit (measured break-even on clusters of ever smaller triangles,
 // profiles/r02_fp16_vs_fp32_nodes.txt: fp16 nodes win by 2 ... 35 % up to 2.6, lose 6 ... 18 % from 4.0) and the area-weighted
-// ratio below kHalfAreaLimit.  Then: the five-waves-per-SIMD kernel; when five workgroups' lane stacks do not fit a CU's LDS
-// (trees deeper than ~28 levels) the same kernel with the stack's tail in global memory.  fp32 nodes otherwise, with triangle
-// rounds at 8 lanes above kLargeSceneTris.
+// ratio below kHalfAreaLimit.  Then: the five-waves-per-SIMD kernel; above kWindowSceneTris triangles, or when five workgroups'
+// lane stacks would not fit a CU's LDS (trees deeper than ~28 levels), its large-scene twin: shade rounds at 24 parked lanes
+// instead of 40 and a sliding 16-entry stack window in LDS (profiles/r03_sweep_large_scenes.txt: 18 ... 24 % faster from 82 k to
+// 1.31 M triangles, 5 % slower at 20 k).  fp32 nodes otherwise, with triangle rounds at 8 lanes above kLargeSceneTris.
 constexpr int kVariantSync = 0, kVariantF32 = 1, kVariantF32Stats = 2, kVariantF32Large = 3, kVariantFastMath = 4;
 constexpr int kVariantF16 = 5, kVariantF16Stats = 6, kVariantF16W5 = 7, kVariantLights = 8, kVariantF16W5Deep = 9;
 constexpr int kVariantWf16 = 10, kVariantWf10 = 11;      // workgroup-level wavefront kernels (render_wavefront.hip)
 constexpr int kDefaultVariant = kVariantF16W5;
 constexpr uint32_t kLargeSceneTris = 100000;
+constexpr uint32_t kWindowSceneTris = 50000;
 constexpr float kHalfAreaLimit = 1.5f, kHalfInflationLimit = 3.0f;
 
 struct FastDiv { uint32_t mul, sh1, sh2; };     // n / d = (t + ((n - t) >> sh1)) >> sh2, t = mulhi(n, mul)  (render_megakernel.hip fast_div)

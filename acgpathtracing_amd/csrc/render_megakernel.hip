@@ -217,13 +217,35 @@ k_render_pw(const RenderArgsBox B)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     // STACK_CAP > 0: only the first STACK_CAP entries of a lane's stack live in LDS (so that a deep tree does not cost a
-    // resident workgroup); the few rays that ever hold more pending nodes keep the rest in global memory (A.stack_overflow)
-    const uint32_t lds_entries = (STACK_CAP > 0 && A.stack_entries > (uint32_t)STACK_CAP) ? (uint32_t)STACK_CAP : A.stack_entries;
+    // resident workgroup); the few rays that ever hold more pending nodes keep the rest in global memory (A.stack_overflow).
+    // STACK_CAP < 0: a SLIDING WINDOW of -STACK_CAP entries (a power of two) in LDS, addressed circularly: slot k of a lane's
+    // stack sits at position k mod window; slots below `wbase` have been moved to global memory.  Pushes and pops inside the
+    // BVH loop are plain circular LDS accesses — no comparison, no branch; once per trip a lane whose stack pointer has come
+    // within a trip's reach of either end of the window moves four entries out or back in (rare: rays seldom hold more than a
+    // dozen pending nodes).  Any tree depth at a fixed LDS cost, and none of the per-access test that made the capped
+    // kernel 10 % slower than the plain one on the same tree.
+    constexpr bool WINDOW = STACK_CAP < 0;
+    constexpr int WIN = WINDOW ? -STACK_CAP : 0;
+    static_assert(!WINDOW || ((WIN & (WIN - 1)) == 0 && WIN >= 16), "the window wraps by masking and must hold two trips");
+    const uint32_t lds_entries = WINDOW ? (uint32_t)WIN + 1u : ((STACK_CAP > 0 && A.stack_entries > (uint32_t)STACK_CAP) ? (uint32_t)STACK_CAP : A.stack_entries);   // WINDOW: entry WIN of a lane's column holds its window base
+    const bool deep = WINDOW && A.stack_entries > (uint32_t)WIN;      // wave-uniform: can a stack outgrow the window at all?
     LaneStack st;
     st.base = lds_dyn + wave * (lds_entries * 64u) + lane;
-    uint32_t* const ovf = STACK_CAP > 0 ? A.stack_overflow + (size_t)(blockIdx.x * (THREADS / 64) + wave) * 64u * (A.stack_entries - lds_entries) + lane : nullptr;
-    const auto push = [&](int at, int v) { if (STACK_CAP == 0 || at < (int)lds_entries) st.push(at, v); else ovf[(at - (int)lds_entries) * 64] = (uint32_t)v; };
-    const auto pop = [&](int at) -> int { if (STACK_CAP == 0 || at < (int)lds_entries) return st.pop(at); return (int)ovf[(at - (int)lds_entries) * 64]; };
+    // the overflow region of this wave: a wave-uniform base (scalar registers) and, where an entry is touched, a 32-bit
+    // offset from the entry number and the lane — a per-lane 64-bit pointer held across the kernel cost two vector registers
+    // and, at the 96 of five waves per SIMD, spills whose scratch traffic was the 18 GB of fabric writes of round 2's profile
+    uint32_t* const ovf = STACK_CAP != 0
+        ? A.stack_overflow + (size_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (THREADS / 64) + wave)) * 64u * (WINDOW ? A.stack_entries : A.stack_entries - lds_entries) : nullptr;
+    const auto push = [&](int at, int v) {
+        if (WINDOW) st.push(at & (WIN - 1), v);
+        else if (STACK_CAP == 0 || at < (int)lds_entries) st.push(at, v);
+        else ovf[(uint32_t)(at - (int)lds_entries) * 64u + lane] = (uint32_t)v;
+    };
+    const auto pop = [&](int at) -> int {
+        if (WINDOW) return st.pop(at & (WIN - 1));
+        if (STACK_CAP == 0 || at < (int)lds_entries) return st.pop(at);
+        return (int)ovf[(uint32_t)(at - (int)lds_entries) * 64u + lane];
+    };
     LaneStack2 st2;                                   // NODE_FMT 3: the same LDS region as stack_entries / 2 groups
     st2.base = (uint2*)(lds_dyn + wave * (lds_entries * 64u)) + lane;
     DeviceScene sc = A.scene;
@@ -297,7 +319,7 @@ k_render_pw(const RenderArgsBox B)
                     { const RenderArgs& Rs = late(); setup_ray<NODE_FMT>(ro, rd, Rs.scene.grid, Rs.scene.hspace, rinv, gro); }
                     if (NODE_FMT == 8) rot = axis_rot(rinv);
                     rtmax = Ldist - 0.01f; best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu;
-                    node = root; sp = 0; cur_list = 0u; shadow_ray = true; shadow_hit = false; started_shadow = true;
+                    node = root; sp = 0; if (WINDOW && deep) st.push(WIN, 0); cur_list = 0u; shadow_ray = true; shadow_hit = false; started_shadow = true;
                 } else {
                     segment_done = true;
                 }
@@ -376,7 +398,7 @@ k_render_pw(const RenderArgsBox B)
             { const RenderArgs& Rs = late(); setup_ray<NODE_FMT>(ro, rd, Rs.scene.grid, Rs.scene.hspace, rinv, gro); }
             if (NODE_FMT == 8) rot = axis_rot(rinv);
             rtmax = 1e16f; best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu;
-            node = root; sp = 0; cur_list = 0u; shadow_ray = false;
+            node = root; sp = 0; if (WINDOW && deep) st.push(WIN, 0); cur_list = 0u; shadow_ray = false;
         }
         n_radiance += (unsigned long long)popc(vote(start_radiance));
 
@@ -429,6 +451,30 @@ k_render_pw(const RenderArgsBox B)
                     }
                 }
                 continue;
+            }
+            if (WINDOW && deep) {
+                // a trip pushes at most TRIP entries (slots sp .. sp + TRIP - 1 must lie inside the window) and pops at most
+                // TRIP + LEAVES (down to slot sp - TRIP - LEAVES, which must not have been moved out)
+                constexpr int TRIP = INNER >= 2 ? INNER : 1;
+                static_assert(!WINDOW || WIN >= 2 * TRIP + LEAVES + 3, "window too small: moving entries out and back in would alternate");
+                // slots [0, wbase) of this lane's stack are in global memory; wbase lives in LDS (entry WIN of the lane's column): one
+                // conflict-free read per trip instead of a vector register held across the shade phase
+                int wbase = st.pop(WIN);
+                for (;;) {
+                    const bool out = act && sp + TRIP > wbase + WIN;
+                    const bool in = act && wbase > 0 && sp - (TRIP + LEAVES) < wbase;
+                    if (vote(out || in) == 0ull) break;
+                    if (out) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) ovf[(uint32_t)(wbase + j) * 64u + lane] = (uint32_t)st.pop((wbase + j) & (WIN - 1));
+                        wbase += 4;
+                    } else if (in) {
+                        wbase -= 4;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) st.push((wbase + j) & (WIN - 1), (int)ovf[(uint32_t)(wbase + j) * 64u + lane]);
+                    }
+                    if (out || in) st.push(WIN, wbase);
+                }
             }
             // INNER == 2: two node visits per trip through the loop control (a lane that reaches a leaf or runs dry in the
             // first sits out the second)
@@ -1055,9 +1101,9 @@ static const VariantDesc kVariants[] = {
     {PW(48, 12, 0, 256, 4, false, 3, 1, 1, false, 0), 256, 0, "FAST-MATH hardware sin/cos + algebraic acos in the cosine-weighted sampler (opt-in; other bits than the default)", 0, PWN(48, 12, 0, 256, 4, false, 3, 1, 1, false, 0)},
     {PW(44, 16, 8, 256, 4, false, 0, 3, 2, false, 0), 256, 8, "pw K44 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes, w4, three visits and two triangle tests per loop trip", 0, PWN(44, 16, 8, 256, 4, false, 0, 3, 2, false, 0)},
     {PW(44, 16, 9, 256, 4, true, 0, 5, 2, false, 0), 256, 9, "pw K44 L16 fp16 sign-rotated nodes, five visits per trip + scheduler stats (the default kernel's loop at four waves)", 0, PWN(44, 16, 9, 256, 4, true, 0, 5, 2, false, 0)},
-    {PW(44, 16, 9, 256, 5, false, 0, 5, 2, false, 0), 256, 9, "pw K44 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes with the rotate amounts in the multipliers' low bits, FIVE waves per SIMD (96 registers), five visits and two triangle tests per loop trip", 0, PWN(44, 16, 9, 256, 5, false, 0, 5, 2, false, 0)},
+    {PW(40, 16, 9, 256, 5, false, 0, 5, 2, false, 0), 256, 9, "pw K40 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes with the rotate amounts in the multipliers' low bits, FIVE waves per SIMD (96 registers), five visits and two triangle tests per loop trip", 0, PWN(40, 16, 9, 256, 5, false, 0, 5, 2, false, 0)},
     {PW(44, 16, 9, 256, 4, false, 0, 5, 2, true, 0), 256, 9, "LIGHTS scene-driven area lights + MIS (light mode 1, opt-in: not the reference's estimator), fp16 sign-rotated nodes w4", 0, PWN(44, 16, 9, 256, 4, false, 0, 5, 2, true, 0)},
-    {PW(44, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "pw K44 L16 fp16 sign-rotated nodes, five waves per SIMD for deep trees: 28 stack entries per lane in LDS, deeper ones in global memory", 28, PWN(44, 16, 9, 256, 5, false, 0, 5, 2, false, 28)},
+    {PW(24, 16, 9, 256, 5, false, 0, 5, 2, false, -16), 256, 9, "pw K24 L16 fp16 sign-rotated nodes, five waves per SIMD, for large scenes and deep trees: shade rounds at 24 parked lanes (rays are long there), a sliding window of 16 stack entries per lane in LDS, deeper ones moved to global memory four at a time", -16, PWN(24, 16, 9, 256, 5, false, 0, 5, 2, false, -16)},
     {nullptr, 0, 9, nullptr, 0, nullptr, 0},      // kVariantWf16: filled from render_wavefront.hip's table (variant_desc)
     {nullptr, 0, 9, nullptr, 0, nullptr, 1},      // kVariantWf10
     {nullptr, 0, 9, nullptr, 0, nullptr, 2},
@@ -1078,6 +1124,38 @@ static const VariantDesc kVariants[] = {
     {PW(44, 4, 9, 256, 5, false, 0, 2, 1, false, 0), 256, 9, "r3 K44 L4 V2 T1"},
     {PW(44, 24, 9, 256, 5, false, 0, 5, 2, false, 0), 256, 9, "r3 K44 L24 V5 T2"},
     {PW(44, 32, 9, 256, 5, false, 0, 5, 2, false, 0), 256, 9, "r3 K44 L32 V5 T2"},
+    {PW(44, 16, 9, 256, 4, false, 0, 5, 2, false, 0), 256, 9, "r3 the default loop at FOUR waves per SIMD (128 registers), whole stack in LDS"},
+    {PW(44, 16, 9, 256, 4, false, 0, 5, 2, false, 28), 256, 9, "r3 four waves per SIMD, 28 stack entries in LDS", 28},
+    // the deep-tree kernel (1.31 M triangles: 27.7 visits per ray): when to leave the BVH loop for a shade round, how long a trip is
+    {PW(36, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K36 L16 V5 T2", 28},
+    {PW(28, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K28 L16 V5 T2", 28},
+    {PW(20, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K20 L16 V5 T2", 28},
+    {PW(44, 8, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K44 L8 V5 T2", 28},
+    {PW(44, 16, 9, 256, 5, false, 0, 8, 2, false, 28), 256, 9, "r3 deep K44 L16 V8 T2", 28},
+    {PW(32, 8, 9, 256, 5, false, 0, 8, 2, false, 28), 256, 9, "r3 deep K32 L8 V8 T2", 28},
+    {PW(52, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K52 L16 V5 T2", 28},
+    {PW(20, 12, 9, 256, 5, false, 0, 5, 2, false, -16), 256, 9, "r3 window-16 K20 L12 V5 T2", -16},
+    {PW(44, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r2's deep-tree kernel: K44 L16, 28 stack entries in LDS, the rest in global memory, tested per access", 28},
+    {PW(36, 16, 9, 256, 5, false, 0, 5, 2, false, -16), 256, 9, "r3 window-16 K36 L16 V5 T2", -16},
+    {PW(44, 16, 9, 256, 5, false, 0, 5, 2, false, -16), 256, 9, "r3 window-16 K44 L16 V5 T2", -16},
+    {PW(20, 12, 9, 256, 5, false, 0, 5, 2, false, -32), 256, 9, "r3 window-32 K20 L12 V5 T2", -32},
+    {PW(20, 12, 9, 256, 6, false, 0, 5, 2, false, -16), 256, 9, "r3 window-16 K20 L12 V5 T2, SIX waves per SIMD", -16},
+    {PW(28, 12, 9, 256, 5, false, 0, 5, 2, false, -16), 256, 9, "r3 window-16 K28 L12 V5 T2", -16},
+    {PW(16, 12, 9, 256, 5, false, 0, 5, 2, false, -16), 256, 9, "r3 window-16 K16 L12 V5 T2", -16},
+    {PW(8, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K8 L16 V5 T2", 28},
+    {PW(12, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K12 L16 V5 T2", 28},
+    {PW(16, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K16 L16 V5 T2", 28},
+    {PW(24, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K24 L16 V5 T2", 28},
+    {PW(16, 8, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K16 L8 V5 T2", 28},
+    {PW(20, 8, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K20 L8 V5 T2", 28},
+    {PW(24, 8, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K24 L8 V5 T2", 28},
+    {PW(20, 12, 9, 256, 5, false, 0, 4, 2, false, 28), 256, 9, "r3 deep K20 L12 V4 T2", 28},
+    {PW(20, 12, 9, 256, 5, false, 0, 6, 2, false, 28), 256, 9, "r3 deep K20 L12 V6 T2", 28},
+    // the same question for the L2-resident scenes (whole stack in LDS)
+    {PW(36, 16, 9, 256, 5, false, 0, 5, 2, false, 0), 256, 9, "r3 K36 L16 V5 T2"},
+    {PW(28, 16, 9, 256, 5, false, 0, 5, 2, false, 0), 256, 9, "r3 K28 L16 V5 T2"},
+    {PW(44, 16, 9, 256, 5, false, 0, 5, 2, false, 0), 256, 9, "r2's default kernel: K44 L16 V5 T2"},
+    {PW(48, 16, 9, 256, 5, false, 0, 5, 2, false, 0), 256, 9, "r3 K48 L16 V5 T2"},
 #if ACGPT_EXPERIMENTS >= 2
     {k_render_pw<40, 8, 0, 256, 4, false, 0, 1>, 256, 0, "pw K40 L8 fp32 w4, register stack top"},
     {k_render_pw<48, 8, 0, 256, 4, false>, 256, 0, "pw K48 L8 fp32 w4, LDS-only stack"},
@@ -1178,6 +1256,7 @@ static size_t variant_lds(const VariantDesc& d, uint32_t stack_entries, uint32_t
 {
     if (d.wf >= 0) return wf_lds_bytes(*wf_variant(d.wf), stack_entries);
     if (d.stack_cap > 0 && stack_entries > (uint32_t)d.stack_cap) stack_entries = (uint32_t)d.stack_cap;
+    if (d.stack_cap < 0) stack_entries = (uint32_t)(-d.stack_cap) + 1u;      // sliding window: that many entries, whatever the tree, + the window base
     size_t lds = (size_t)(d.threads / 64) * (stack_entries * 256u + kBookDwords * 4u) + 256u;      // lane stacks, fold bookkeeping, LCG skip-ahead table
     if (d.node_fmt == 2) lds += (size_t)n_nodes * sizeof(QNode);
     return lds;
