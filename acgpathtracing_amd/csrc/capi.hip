@@ -59,6 +59,7 @@ struct pt_ctx {
     size_t scratch_limit = (size_t)1 << 30;                          // a frame batch is cut into launches whose frame sums fit
     // division constants of the tile order, valid for (div_width, div_world_n): built and verified once per image width
     uint32_t div_width = 0; int div_world_n = 0; ptd::FastDiv div_cols = {0, 0, 0}, div_world = {0, 0, 0};
+    int queue_order = 1;                      // tile-strip rows dealt round robin over the queue shards (render_common.h queue_slot; pt_debug_queue_order)
     pt_multi* multi = nullptr;                // pt_create_multi: this context is rank 0 of a group (below)
     pt_stats stats;
     uint64_t scene_serial = 0;
@@ -526,7 +527,7 @@ PT_API int pt_set_stream(pt_ctx* c, void* s)
 static ptd::DeviceScene device_scene(pt_ctx* c)
 {
     ptd::DeviceScene sc;
-    sc.nodes = c->bvh.nodes; sc.qnodes = c->bvh.qnodes; sc.cnodes = c->bvh.cnodes; sc.hnodes = c->bvh.hnodes; sc.hspace = c->bvh.hspace; sc.grid = c->bvh.grid; sc.tris = c->bvh.tris; sc.shade = c->bvh.shade; sc.wrecs = c->bvh.wrecs; sc.mats = c->d_mats;
+    sc.nodes = c->bvh.nodes; sc.qnodes = c->bvh.qnodes; sc.cnodes = c->bvh.cnodes; sc.hnodes = c->bvh.hnodes; sc.top = c->bvh.top_nodes; sc.n_top = c->bvh.n_top; sc.hspace = c->bvh.hspace; sc.grid = c->bvh.grid; sc.tris = c->bvh.tris; sc.shade = c->bvh.shade; sc.wrecs = c->bvh.wrecs; sc.mats = c->d_mats;
     sc.n_tris = c->bvh.n_tris; sc.n_mats = c->n_mats;
     sc.lights = c->d_lights; sc.n_lights = c->n_lights; sc.light_area = c->light_area;
     return sc;
@@ -753,6 +754,8 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
     a.div_cols = c->div_cols;
     a.div_world = c->div_world;
     a.shard_size = ((a.total_samples + 7u) / 8u + 63u) & ~63u;
+    a.row_interleave = (uint32_t)c->queue_order;
+    a.strip_rows = p->height / 4u + (p->height % 4u == 0 ? 0u : 1u);
     {   // one float4 per (pixel slot of this rank's tile order, sub-frame): what the megakernel hands to k_finalize
         const size_t need = (size_t)num_samples(c->world, p->width, p->height) * n_frames * sizeof(float4);
         if (need > c->frame_sums_bytes) {
@@ -991,6 +994,14 @@ PT_API int pt_debug_queue_progress(pt_ctx* c, uint64_t* out)
     if (!c || !out) return fail(c, "pt_debug_queue_progress: null argument");
     CK(c, hipSetDevice(c->device));
     CK(c, hipMemcpy(out, c->d_counters + 8 + 3 * (size_t)ptd::kMaxTimedWaves, 2056 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+PT_API int pt_debug_queue_order(pt_ctx* c, int mode)
+{
+    if (!c || mode < 0 || mode > 5) return fail(c, "pt_debug_queue_order: 0 = contiguous eighths of the tile order per shard; round robin over the shards in units of 1 = a tile-strip row, 2 = a tile, 3 / 4 = two / four rows");
+    c->queue_order = mode;
+    if (c->multi) for (size_t i = 1; i < c->multi->ranks.size(); i++) c->multi->ranks[i]->queue_order = mode;
     return 0;
 }
 

@@ -13,6 +13,8 @@ struct LbvhResult {
     QNode*     qnodes = nullptr;       // device, n_nodes (16-bit grid boxes, 32 B)
     BvhNode*   cnodes = nullptr;       // device, n_nodes (centre + half-extent boxes, 64 B)
     HNode*     hnodes = nullptr;       // device, n_nodes (fp16 boxes, 32 B)
+    HNode*     top_nodes = nullptr;    // device, kTopNodesMax: the first n_top inner nodes breadth first (children inside the array: kTopNodeFlag | position)
+    uint32_t   n_top = 0;
     HSpace     hspace = {0, 0, 0, 1};
     float      half_area_ratio = 0.0f; // sum of child-box areas after fp16 outward rounding / before (what a random ray pays)
     float      half_box_inflation = 0.0f; // mean over the child boxes of their own area after / before (what a ray through the finest geometry pays)

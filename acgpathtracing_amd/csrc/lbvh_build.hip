@@ -544,6 +544,27 @@ __global__ void k_half_nodes(const BvhNode* __restrict__ nodes, uint32_t n, HSpa
     if ((threadIdx.x & 63) == 0) { atomicAdd(&area[0], before); atomicAdd(&area[1], after); atomicAdd(&area[2], boxes); atomicAdd(&area[3], inflation); }
 }
 
+// --- 9. the top of the tree, breadth first ---------------------------------------------------------------------------------
+// The first `cap` inner nodes in breadth-first order from the root, as a small array of their own: a child that is in the
+// array too is referenced as kTopNodeFlag | position, every other child as in `hn`.  Render kernels that stage the top of the
+// tree in LDS (every ray walks it) traverse this copy.  One thread: 255 nodes at most.
+// ids[i] = index in `hn` of the node at position i (a kernel that stages fewer than `cap` nodes turns references past its
+// own cut back into those).
+__global__ void k_top_nodes(const HNode* __restrict__ hn, HNode* __restrict__ top, uint32_t* __restrict__ ids, uint32_t cap, uint32_t* __restrict__ n_out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t count = 1;
+    ids[0] = 0u;
+    for (uint32_t i = 0; i < count; i++) {
+        HNode nd = hn[ids[i]];
+        const int c0 = (int)nd.a.w, c1 = (int)nd.b.w;
+        if (c0 >= 0 && count < cap) { ids[count] = (uint32_t)c0; nd.a.w = kTopNodeFlag | count; count++; }
+        if (c1 >= 0 && count < cap) { ids[count] = (uint32_t)c1; nd.b.w = kTopNodeFlag | count; count++; }
+        top[i] = nd;
+    }
+    *n_out = count;
+}
+
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); return false; } } while (0)
 
 namespace {
@@ -572,6 +593,7 @@ void free_lbvh(LbvhResult& r)
     if (r.qnodes) (void)hipFree(r.qnodes);
     if (r.cnodes) (void)hipFree(r.cnodes);
     if (r.hnodes) (void)hipFree(r.hnodes);
+    if (r.top_nodes) (void)hipFree(r.top_nodes);
     if (r.tris) (void)hipFree(r.tris);
     if (r.shade) (void)hipFree(r.shade);
     if (r.wrecs) (void)hipFree(r.wrecs);
@@ -711,6 +733,12 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
         k_half_nodes<<<(n_nodes + 255) / 256, 256, 0, stream>>>(out.nodes, n_nodes, sp, out.hnodes, d_area);
         HIPCK(hipGetLastError());
         HIPCK(hipMemcpyAsync(h_area, d_area, 16, hipMemcpyDeviceToHost, stream));
+        uint32_t* d_ntop;
+        HIPCK(sc.alloc(&d_ntop, 4));
+        HIPCK(hipMalloc((void**)&out.top_nodes, (size_t)kTopNodesMax * (sizeof(HNode) + sizeof(uint32_t))));      // nodes, then their indices in hnodes
+        k_top_nodes<<<1, 64, 0, stream>>>(out.hnodes, out.top_nodes, (uint32_t*)(out.top_nodes + kTopNodesMax), kTopNodesMax, d_ntop);
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(&out.n_top, d_ntop, 4, hipMemcpyDeviceToHost, stream));
         HIPCK(hipStreamSynchronize(stream));
         out.hspace = sp;
         out.half_area_ratio = h_area[0] > 0.0f ? h_area[1] / h_area[0] : 1.0f;

@@ -59,7 +59,9 @@ struct __attribute__((aligned(16))) HNode {
     uint4 b;
 };
 static_assert(sizeof(HNode) == 32, "hnode size");
-struct HSpace { float cx, cy, cz, inv_scale; };     // world = g * inv_scale + centre; inv_scale is a power of two
+struct HSpace { float cx, cy, cz, inv_scale; };
+constexpr uint32_t kTopNodeFlag = 0x40000000u;      // node reference into the breadth-first copy of the tree's top (DeviceScene::top)
+constexpr uint32_t kTopNodesMax = 255u;     // world = g * inv_scale + centre; inv_scale is a power of two
 
 // world -> grid: g = (w - origin) * inv_cell ; cell sizes per axis
 struct QGrid {
@@ -73,6 +75,8 @@ struct DeviceScene {
     const QNode*       qnodes;
     const BvhNode*     cnodes;    // the same tree with every child box as centre + half extent (layout of BvhNode: lo -> centre, hi -> half extent)
     const HNode*       hnodes;    // the same tree with fp16 boxes (32-byte nodes)
+    const HNode*       top;       // its first n_top inner nodes, breadth first (lbvh_build.hip k_top_nodes)
+    uint32_t           n_top;
     HSpace             hspace;
     QGrid              grid;
     const TriRecord*   tris;

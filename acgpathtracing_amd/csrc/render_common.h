@@ -87,6 +87,36 @@ __device__ __forceinline__ void sample_pixel_fast(const RenderArgs& A, uint32_t 
     px = tile_strip_x * (8u * world) + (tile_pixel_idx & 7u) + tile_offset_x;
 }
 
+// Queue position of a pixel slot -> the pixel slot it stands for.  The queue is cut into eight contiguous shards, one per XCD;
+// with the identity (A.row_interleave 0) a shard is a contiguous band of the image, and bands differ in cost: XCDs drift apart
+// by up to a fifth of the launch and even out only by stealing at the end (profiles/r02_wave_timeline.txt).  Otherwise the
+// image is dealt in units — 1: a tile-strip row (4 pixel rows), 2: one 8x4 tile, 3 / 4: two / four tile-strip rows — and the
+// units go to the shards round robin (unit u to shard u mod 8, what sutil/WorkDistribution.h:60-81 does across GPUs): queue
+// order = units 0, 8, 16, ..., 1, 9, 17, ...
+__device__ __forceinline__ uint32_t queue_slot(const RenderArgs& A, uint32_t pos)
+{
+    const uint32_t mode = A.row_interleave;
+    if (mode == 0u || mode == 5u) return pos;          // 5 (experiment): identity, and every wave starts at shard 0: one queue in image order
+    const uint32_t tile = pos >> 5;
+    uint32_t k, within, unit_tiles, n_units;           // unit position in queue order, tile within the unit
+    if (mode == 2u) { k = tile; within = 0u; unit_tiles = 1u; n_units = A.strip_rows * A.strip_cols; }
+    else {
+        const uint32_t sh = mode == 1u ? 0u : (mode == 3u ? 1u : 2u);
+        const uint32_t row = fast_div(tile, A.div_cols);
+        k = row >> sh;
+        unit_tiles = A.strip_cols << sh;
+        within = tile - k * unit_tiles;
+        n_units = (A.strip_rows + (1u << sh) - 1u) >> sh;
+    }
+    uint32_t unit = k;
+    for (uint32_t s = 0; s < 8u; s++) {
+        const uint32_t n_s = n_units > s ? (n_units - s + 7u) >> 3 : 0u;     // units congruent to s modulo 8
+        if (k < n_s) { unit = k * 8u + s; break; }
+        k -= n_s;
+    }
+    return ((unit * unit_tiles + within) << 5) | (pos & 31u);
+}
+
 // lcg_skip: {multiplier, increment} of the LCG skip-ahead per run, staged in LDS by the kernel (a per-lane table look-up
 // in the kernel-argument segment would be a global load on the deal's critical path)
 template <bool STATS = false>
@@ -126,7 +156,7 @@ __device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q,
                 q.grant_g0 = first >> cs;
                 const uint32_t g = q.grant_g0 + lane;
                 uint32_t x, y;
-                sample_pixel_fast(A, g >> fshift, x, y);
+                sample_pixel_fast(A, queue_slot(A, g >> fshift), x, y);
                 const uint32_t f = g & fmask;
                 const bool ok = (g << cs) < first + avail && x < A.width && y < A.height && f < A.n_frames;   // else: padding of the tile / batch grid
                 q.grp_pxy = ok ? (x | (y << 16)) : 0xFFFFFFFFu;

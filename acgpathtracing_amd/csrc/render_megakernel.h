@@ -68,6 +68,8 @@ struct RenderArgs {
     uint32_t  strip_cols;      // tile-strip columns of StaticWorkDistribution for (width, world)
     FastDiv   div_cols, div_world;
     pt_float3 cull_lo, cull_hi;   // scene bounding box, enlarged: a camera ray that misses it ends its path without a traversal
+    uint32_t  row_interleave;     // 1 (experiment, pt_debug_queue_order): queue position -> tile-strip row 0, 8, 16, ..., 1, 9, ... so that every
+    uint32_t  strip_rows;         // queue shard (one per XCD) holds rows from all over the image instead of a contiguous eighth
 };
 
 int render_variant_count();

@@ -72,7 +72,7 @@ k_render(const RenderArgsBox B)
     const float fw = (float)(int)A.width, fh = (float)(int)A.height;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-    QueueState q; q.shard = xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.grant_g0 = 0; q.grp_pxy = 0xFFFFFFFFu; q.grp_seed = 0; q.free_top = kFoldSlots;
+    QueueState q; q.shard = A.row_interleave == 5u ? 0u : xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.grant_g0 = 0; q.grp_pxy = 0xFFFFFFFFu; q.grp_seed = 0; q.free_top = kFoldSlots;
     unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0;
     float* const scratch = A.wave_scratch + 3u * (size_t)(blockIdx.x * (kRenderThreads / 64) + wave) * ((size_t)kFoldSlots << A.chunk_shift);
 
@@ -209,7 +209,7 @@ __device__ __forceinline__ void setup_ray(const f3& ro, const f3& rd, const QGri
 // INNER: 0 = stack entirely in LDS, nested branches; 1 = stack top cached in a register (the LDS read of
 // a pop is consumed one push/pop later, off the critical path) and child selection by selects; 2, 3 = the same with
 // that many node visits per trip through the loop control.
-template <int SHADE_K, int LEAF_K, int NODE_FMT, int THREADS, int MINW, bool STATS, int DIAG = 0, int INNER = 0, int LEAVES = 1, bool LIGHTS = false, int STACK_CAP = 0>
+template <int SHADE_K, int LEAF_K, int NODE_FMT, int THREADS, int MINW, bool STATS, int DIAG = 0, int INNER = 0, int LEAVES = 1, bool LIGHTS = false, int STACK_CAP = 0, int TOPN = 0>
 __global__ void __launch_bounds__(THREADS, MINW)
 k_render_pw(const RenderArgsBox B)
 {
@@ -261,11 +261,25 @@ k_render_pw(const RenderArgsBox B)
     uint32_t* const lcg_skip = lds_dyn + (THREADS / 64) * (lds_entries * 64u) + (NODE_FMT == 2 ? A.n_lds_nodes * 8u : 0u);
     if (threadIdx.x < 32u) { lcg_skip[2u * threadIdx.x] = A.lcg_mul[threadIdx.x]; lcg_skip[2u * threadIdx.x + 1u] = A.lcg_add[threadIdx.x]; }
     const WaveBook book = wave_book(lcg_skip + 64u + wave * kBookDwords, lane);
+    // TOPN > 0 (experiment): the first TOPN nodes of the tree, breadth first, staged in LDS behind the books — every ray walks them;
+    // a node reference with kTopNodeFlag is a position in that copy
+    const uint4* const top_lds = (const uint4*)(lcg_skip + 64u + (THREADS / 64) * kBookDwords);
+    if (TOPN > 0) {
+        uint4* dst = (uint4*)(lcg_skip + 64u + (THREADS / 64) * kBookDwords);
+        const uint4* src = (const uint4*)A.scene.top;
+        const uint32_t n = (A.scene.n_top < (uint32_t)TOPN ? A.scene.n_top : (uint32_t)TOPN) * 2u;
+        const uint32_t* ids = (const uint32_t*)(A.scene.top + kTopNodesMax);        // position -> index in hnodes
+        for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
+            uint4 v = src[i];
+            if ((int)v.w >= 0 && (v.w & kTopNodeFlag) && (v.w & 0xFFFFu) >= (uint32_t)TOPN) v.w = ids[v.w & 0xFFFFu];     // a child past this kernel's cut: back to its index in hnodes
+            dst[i] = v;
+        }
+    }
     __syncthreads();
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int root = sc.n_tris ? 0 : kSentinel;
+    const int root = sc.n_tris ? ((TOPN > 0 && NODE_FMT == 9) ? (int)kTopNodeFlag : 0) : kSentinel;
 
-    QueueState q; q.shard = xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.grant_g0 = 0; q.grp_pxy = 0xFFFFFFFFu; q.grp_seed = 0; q.free_top = kFoldSlots;
+    QueueState q; q.shard = A.row_interleave == 5u ? 0u : xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.grant_g0 = 0; q.grp_pxy = 0xFFFFFFFFu; q.grp_seed = 0; q.free_top = kFoldSlots;
     float* const scratch = A.wave_scratch + 3u * (size_t)(blockIdx.x * (THREADS / 64) + wave) * ((size_t)kFoldSlots << A.chunk_shift);
     unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0, n_culled = 0;
     unsigned long long n_steps = 0, n_lane_steps = 0, n_rounds = 0, n_lane_rounds = 0;
@@ -544,8 +558,14 @@ k_render_pw(const RenderArgsBox B)
                     f1 = fminf(fminf(fma_h_hi(bx, rinv.x, gro.x), fma_h_hi(by, rinv.y, gro.y)), fma_h_hi(bz, rinv.z, gro.z)) * kFarWiden;
                 } else if (NODE_FMT == 9) {
                     // NODE_FMT 8 with the rotate amounts read from the low bits of the plane multipliers (setup_ray)
-                    const uint4* np = (const uint4*)((const char*)sc.hnodes + (size_t)((uint32_t)node << 5));
-                    const uint4 qa = np[0], qb = np[1];
+                    uint4 qa, qb;
+                    if (TOPN > 0 && ((uint32_t)node & kTopNodeFlag)) {             // the top of the tree: from LDS
+                        const uint4* tp = top_lds + 2u * ((uint32_t)node & 0xFFFFu);
+                        qa = tp[0]; qb = tp[1];
+                    } else {
+                        const uint4* np = (const uint4*)((const char*)sc.hnodes + (size_t)((uint32_t)node << 5));
+                        qa = np[0]; qb = np[1];
+                    }
                     c0 = (int)qa.w; c1 = (int)qb.w;
                     slab_h9(qa.x, qa.y, qa.z, rinv, gro, rtmin, n0, f0);
                     slab_h9(qb.x, qb.y, qb.z, rinv, gro, rtmin, n1, f1);
@@ -1083,7 +1103,7 @@ hipError_t trace_stream_occupancy(int fmt, uint32_t stack_entries, int* blocks_p
 }
 
 // ---- host-side launchers ------------------------------------------------------------------
-struct VariantDesc { RenderKernel k; int threads; int node_fmt; const char* name; int stack_cap = 0; const char* kernel = ""; int wf = -1; };   // wf >= 0: index into render_wavefront.hip's table
+struct VariantDesc { RenderKernel k; int threads; int node_fmt; const char* name; int stack_cap = 0; const char* kernel = ""; int wf = -1; int top_n = 0; };   // wf >= 0: index into render_wavefront.hip's table
 
 // Render kernel variants.  0: segment-synchronous (fp32 nodes).  Others: persistent traversal
 // <SHADE_K, LEAF_K, NODE_FMT, THREADS, MINW, STATS, DIAG, INNER, LEAVES, LIGHTS, STACK_CAP>.  The product library carries the
@@ -1136,6 +1156,12 @@ static const VariantDesc kVariants[] = {
     {PW(52, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K52 L16 V5 T2", 28},
     {PW(20, 12, 9, 256, 5, false, 0, 5, 2, false, -16), 256, 9, "r3 window-16 K20 L12 V5 T2", -16},
     {PW(44, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r2's deep-tree kernel: K44 L16, 28 stack entries in LDS, the rest in global memory, tested per access", 28},
+    // the top of the tree from LDS instead of through the texture-address path
+    {PW(40, 16, 9, 256, 5, false, 0, 5, 2, false, 0, 15), 256, 9, "r3 default + top 15 nodes in LDS", 0, "", -1, 15},
+    {PW(40, 16, 9, 256, 5, false, 0, 5, 2, false, 0, 63), 256, 9, "r3 default + top 63 nodes in LDS", 0, "", -1, 63},
+    {PW(40, 16, 9, 256, 5, false, 0, 5, 2, false, -16, 255), 256, 9, "r3 K40 window-16 + top 255 nodes in LDS", -16, "", -1, 255},
+    {PW(24, 16, 9, 256, 5, false, 0, 5, 2, false, -16, 63), 256, 9, "r3 large-scene kernel + top 63 nodes in LDS", -16, "", -1, 63},
+    {PW(24, 16, 9, 256, 5, false, 0, 5, 2, false, -16, 255), 256, 9, "r3 large-scene kernel + top 255 nodes in LDS", -16, "", -1, 255},
     {PW(36, 16, 9, 256, 5, false, 0, 5, 2, false, -16), 256, 9, "r3 window-16 K36 L16 V5 T2", -16},
     {PW(44, 16, 9, 256, 5, false, 0, 5, 2, false, -16), 256, 9, "r3 window-16 K44 L16 V5 T2", -16},
     {PW(20, 12, 9, 256, 5, false, 0, 5, 2, false, -32), 256, 9, "r3 window-32 K20 L12 V5 T2", -32},
@@ -1257,7 +1283,7 @@ static size_t variant_lds(const VariantDesc& d, uint32_t stack_entries, uint32_t
     if (d.wf >= 0) return wf_lds_bytes(*wf_variant(d.wf), stack_entries);
     if (d.stack_cap > 0 && stack_entries > (uint32_t)d.stack_cap) stack_entries = (uint32_t)d.stack_cap;
     if (d.stack_cap < 0) stack_entries = (uint32_t)(-d.stack_cap) + 1u;      // sliding window: that many entries, whatever the tree, + the window base
-    size_t lds = (size_t)(d.threads / 64) * (stack_entries * 256u + kBookDwords * 4u) + 256u;      // lane stacks, fold bookkeeping, LCG skip-ahead table
+    size_t lds = (size_t)(d.threads / 64) * (stack_entries * 256u + kBookDwords * 4u) + 256u + (size_t)d.top_n * sizeof(HNode);      // lane stacks, fold bookkeeping, LCG skip-ahead table, staged top of the tree
     if (d.node_fmt == 2) lds += (size_t)n_nodes * sizeof(QNode);
     return lds;
 }

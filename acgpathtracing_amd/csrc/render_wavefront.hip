@@ -195,7 +195,7 @@ __device__ __forceinline__ void wf_refill(const RenderArgs& A, QueueState& q, ui
             q.grant_g0 = first >> cs;
             const uint32_t g = q.grant_g0 + lane;
             uint32_t x, y;
-            sample_pixel_fast(A, g >> fshift, x, y);
+            sample_pixel_fast(A, queue_slot(A, g >> fshift), x, y);
             const uint32_t f = g & fmask;
             const bool ok = (g << cs) < first + avail && x < A.width && y < A.height && f < A.n_frames;
             q.grp_pxy = ok ? (x | (y << 16)) : 0xFFFFFFFFu;

@@ -54,6 +54,10 @@ int pt_debug_wave_times(pt_ctx* ctx, uint64_t* out, size_t max_waves);
  * 8 * 256 values (0 = never reached by a stamped grant), followed by ONE value: the time all waves together spent
  * in the shade / regenerate phase, in 10 ns units and its split into queue refill / finished runs / camera-path start (2056 values in all: 2048 + 1 + 3, rest unused). */
 int pt_debug_queue_progress(pt_ctx* ctx, uint64_t* out);
+/* Experiment: order of the work queue.  0 (default): each of the eight queue shards (one per XCD) is a contiguous eighth of the
+ * 8x4-tile order; 1: tile-strip rows are dealt round-robin over the shards (what sutil/WorkDistribution.h:60-81 does across
+ * GPUs).  Same image bits either way. */
+int pt_debug_queue_order(pt_ctx* ctx, int mode);
 /* Diagnostic: after a launch of a wavefront kernel variant (render_wavefront.hip), 17 values summed over the waves of the grid,
  * times in 10 ns ticks: trace waves {total, idle}, shade waves {total, idle, deal time / rounds / records, hit-shading time /
  * rounds / records, accounting time / rounds / records}, trace waves {exchange time / exchanges / records taken in, loop trips}. */

@@ -6,4 +6,4 @@ SCENE=$(python3 -c "
 import sys; sys.path.insert(0, '$REPO')
 import bench, acgpathtracing_amd as pt
 print(bench.scene_path(pt, 'stress_1m.obj'))")
-python3 $REPO/tools/sweep_variants.py --scene $SCENE --fuse 2 --chunks 0 --rounds 3 --variants "$1" "${@:2}"
+python3 $REPO/tools/sweep_variants.py --scene $SCENE --fuse 2 --chunks 0 --rounds ${ROUNDS:-3} --variants "$1" "${@:2}"
