@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>      // types only: librccl is loaded with dlopen by pt_create_multi, a single-GPU caller never touches it
 #include <dlfcn.h>
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -59,6 +60,9 @@ struct pt_ctx {
     size_t scratch_limit = (size_t)1 << 30;                          // a frame batch is cut into launches whose frame sums fit
     // division constants of the tile order, valid for (div_width, div_world_n): built and verified once per image width
     uint32_t div_width = 0; int div_world_n = 0; ptd::FastDiv div_cols = {0, 0, 0}, div_world = {0, 0, 0};
+    uint2* d_row_spans = nullptr; size_t row_spans_rows = 0;         // pixel classes per image row (row_spans below)
+    std::vector<float> spans_key;                                    // what the spans on the device were computed from
+    int pixel_classes = 1;                                           // 0: off (pt_debug_pixel_classes)
     int queue_order = 1;                      // tile-strip rows dealt round robin over the queue shards (render_common.h queue_slot; pt_debug_queue_order)
     pt_multi* multi = nullptr;                // pt_create_multi: this context is rank 0 of a group (below)
     pt_stats stats;
@@ -284,6 +288,7 @@ static void destroy_one(pt_ctx* c)
     if (c->d_frame_sums) (void)hipFree(c->d_frame_sums);
     if (c->d_wave_scratch) (void)hipFree(c->d_wave_scratch);
     if (c->d_stack_ovf) (void)hipFree(c->d_stack_ovf);
+    if (c->d_row_spans) (void)hipFree(c->d_row_spans);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -564,6 +569,97 @@ static bool check_fast_div(const ptd::FastDiv& f, uint32_t d, uint32_t n_max)
     return q(0xFFFFFFFFu) == 0xFFFFFFFFu / d;
 }
 
+// ---- pixel classes -------------------------------------------------------------------------------------------------------------
+// The rays through a pixel are D = dx U + dy V + W with (dx, dy) in the pixel's square of the image plane
+// (pathTracerPrograms.cu:730-737).  The rays that meet a convex box are those whose (dx, dy) fall into the convex hull of the
+// box's eight projected corners.  Per image row: the columns outside which a pixel's square lies wholly outside that hull (by
+// a quarter pixel and with the box grown by a thousandth of the scene: no ray through such a pixel can hit anything — the kernel
+// books its samples as misses without starting them), and the columns inside which the square lies wholly inside it (path starts
+// there skip the cull test; a hint only: a ray that misses after all is traversed and misses).  false: the box is not entirely
+// in front of the eye, or the camera frame is degenerate — no classes for this launch.
+static bool row_spans(const pt_params* p, const float lo[3], const float hi[3], std::vector<uint32_t>& out)
+{
+    const uint32_t W = p->width, H = p->height;
+    out.assign((size_t)2 * H, 0u);
+    const double U[3] = {p->cameraU.x, p->cameraU.y, p->cameraU.z}, V[3] = {p->cameraV.x, p->cameraV.y, p->cameraV.z}, Wv[3] = {p->cameraW.x, p->cameraW.y, p->cameraW.z};
+    const double E[3] = {p->cameraEye.x, p->cameraEye.y, p->cameraEye.z};
+    auto cross = [](const double* a, const double* b, double* r) { r[0] = a[1] * b[2] - a[2] * b[1]; r[1] = a[2] * b[0] - a[0] * b[2]; r[2] = a[0] * b[1] - a[1] * b[0]; };
+    auto dot = [](const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+    double VxW[3], WxU[3], UxV[3];
+    cross(V, Wv, VxW); cross(Wv, U, WxU); cross(U, V, UxV);
+    const double det = dot(U, VxW);
+    const double scale = std::sqrt(dot(U, U) * dot(V, V) * dot(Wv, Wv));
+    if (!(std::fabs(det) > 1e-9 * scale) || !std::isfinite(det)) return false;
+    double ext = 0.0;
+    for (int k = 0; k < 3; k++) ext = std::max(ext, (double)hi[k] - (double)lo[k]);
+    if (!(ext >= 0.0) || !std::isfinite(ext)) return false;
+    const double pad = 1e-3 * ext + 1e-6;
+    std::vector<std::pair<double, double>> pts;
+    for (int i = 0; i < 8; i++) {
+        const double c[3] = {((i & 1) ? hi[0] + pad : lo[0] - pad) - E[0], ((i & 2) ? hi[1] + pad : lo[1] - pad) - E[1], ((i & 4) ? hi[2] + pad : lo[2] - pad) - E[2]};
+        const double a = dot(c, VxW) / det, b = dot(c, WxU) / det, t = dot(c, UxV) / det;      // c = a U + b V + t W
+        if (!(t > 1e-6 * (std::fabs(a) + std::fabs(b) + 1.0)) || !std::isfinite(a + b + t)) return false;   // at or behind the eye plane
+        pts.emplace_back(a / t, b / t);
+    }
+    // convex hull (monotone chain), counter-clockwise
+    std::sort(pts.begin(), pts.end());
+    std::vector<std::pair<double, double>> hull(16);
+    int k = 0;
+    auto turn = [](const std::pair<double, double>& o, const std::pair<double, double>& a, const std::pair<double, double>& b) { return (a.first - o.first) * (b.second - o.second) - (a.second - o.second) * (b.first - o.first); };
+    for (int i = 0; i < 8; i++) { while (k >= 2 && turn(hull[k - 2], hull[k - 1], pts[i]) <= 0) k--; hull[k++] = pts[i]; }
+    for (int i = 6, t0 = k + 1; i >= 0; i--) { while (k >= t0 && turn(hull[k - 2], hull[k - 1], pts[i]) <= 0) k--; hull[k++] = pts[i]; }
+    const int n = k - 1;
+    if (n < 3) return false;
+    // the hull's x interval on the horizontal line at height y; false: the line misses the hull
+    auto interval = [&](double y, double& l, double& r) {
+        l = 1e300; r = -1e300;
+        for (int i = 0; i < n; i++) {
+            const auto& a = hull[i]; const auto& b = hull[(i + 1) % n];
+            const double ya = a.second, yb = b.second;
+            if ((ya <= y && y <= yb) || (yb <= y && y <= ya)) {
+                const double x = ya == yb ? a.first : a.first + (b.first - a.first) * (y - ya) / (yb - ya);
+                l = std::min(l, ya == yb ? std::min(a.first, b.first) : x);
+                r = std::max(r, ya == yb ? std::max(a.first, b.first) : x);
+            }
+        }
+        return l <= r;
+    };
+    double ymin = 1e300, ymax = -1e300;
+    for (int i = 0; i < n; i++) { ymin = std::min(ymin, hull[i].second); ymax = std::max(ymax, hull[i].second); }
+    const double mx = 0.5 / W, my = 0.5 / H;                  // a quarter pixel in image-plane units (a pixel is 2 / W wide)
+    for (uint32_t y = 0; y < H; y++) {
+        const double y0 = 2.0 * y / H - 1.0, y1 = 2.0 * (y + 1) / H - 1.0;
+        uint32_t out_lo = 0, out_hi = 0, in_lo = 0, in_hi = 0;
+        if (!(y1 + my < ymin || y0 - my > ymax)) {
+            // outer: the hull's extent over the band [y0 - my, y1 + my] — at the band's two edges (clamped into the hull's own
+            // range) and at every hull vertex inside the band
+            double l = 1e300, r = -1e300, a, b;
+            const double e0 = std::max(y0 - my, ymin), e1 = std::min(y1 + my, ymax);
+            if (interval(e0, a, b)) { l = std::min(l, a); r = std::max(r, b); }
+            if (interval(e1, a, b)) { l = std::min(l, a); r = std::max(r, b); }
+            for (int i = 0; i < n; i++) if (hull[i].second >= e0 && hull[i].second <= e1) { l = std::min(l, hull[i].first); r = std::max(r, hull[i].first); }
+            if (l <= r) {
+                const double fl = std::floor((l - mx + 1.0) * 0.5 * W), fh = std::ceil((r + mx + 1.0) * 0.5 * W);
+                out_lo = (uint32_t)std::min(std::max(fl, 0.0), (double)W);
+                out_hi = (uint32_t)std::min(std::max(fh, 0.0), (double)W);
+            }
+            // inner: columns whose square lies inside the hull — convex, so inside at both edges of the (grown) band is enough
+            double l0, r0, l1, r1;
+            if (interval(y0 - my, l0, r0) && interval(y1 + my, l1, r1)) {
+                const double il = std::max(l0, l1) + mx, ir = std::min(r0, r1) - mx;
+                const double cl = std::ceil((il + 1.0) * 0.5 * W), ch = std::floor((ir + 1.0) * 0.5 * W);
+                if (cl < ch) { in_lo = (uint32_t)std::min(std::max(cl, 0.0), (double)W); in_hi = (uint32_t)std::min(std::max(ch, 0.0), (double)W); }
+                if (in_lo < out_lo) in_lo = out_lo;
+                if (in_hi > out_hi) in_hi = out_hi;
+                if (in_lo >= in_hi) in_lo = in_hi = 0;
+            }
+        }
+        out[2 * (size_t)y] = out_lo | (out_hi << 16);
+        out[2 * (size_t)y + 1] = in_lo | (in_hi << 16);
+    }
+    return true;
+}
+
 PT_API int pt_launch(pt_ctx* c, const pt_params* p) { return pt_launch_frames(c, p, 1u); }
 
 static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames);
@@ -772,6 +868,30 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
         const float grow = ext * (1.0f / 1024.0f) + 1e-6f;
         a.cull_lo = {c->bvh.scene_lo[0] - grow, c->bvh.scene_lo[1] - grow, c->bvh.scene_lo[2] - grow};
         a.cull_hi = {c->bvh.scene_hi[0] + grow, c->bvh.scene_hi[1] + grow, c->bvh.scene_hi[2] + grow};
+    }
+    a.row_spans = nullptr;
+    if (c->pixel_classes && c->bvh.n_tris != 0u && p->height <= 32767u) {
+        // recomputed only when the camera, the image size or the scene box change
+        std::vector<float> key = {(float)p->width, (float)p->height, p->cameraEye.x, p->cameraEye.y, p->cameraEye.z, p->cameraU.x, p->cameraU.y, p->cameraU.z,
+                                  p->cameraV.x, p->cameraV.y, p->cameraV.z, p->cameraW.x, p->cameraW.y, p->cameraW.z,
+                                  c->bvh.scene_lo[0], c->bvh.scene_lo[1], c->bvh.scene_lo[2], c->bvh.scene_hi[0], c->bvh.scene_hi[1], c->bvh.scene_hi[2], 1.0f};
+        if (key != c->spans_key || memcmp(key.data(), c->spans_key.data(), key.size() * sizeof(float)) != 0) {
+            std::vector<uint32_t> spans;
+            const bool ok = row_spans(p, c->bvh.scene_lo, c->bvh.scene_hi, spans);
+            key.back() = ok ? 1.0f : 0.0f;
+            if (ok) {
+                if (c->row_spans_rows < p->height) {
+                    CK(c, hipStreamSynchronize(c->stream));
+                    if (c->d_row_spans) { (void)hipFree(c->d_row_spans); c->d_row_spans = nullptr; c->row_spans_rows = 0; }
+                    CK(c, hipMalloc((void**)&c->d_row_spans, (size_t)p->height * sizeof(uint2)));
+                    c->row_spans_rows = p->height;
+                }
+                CK(c, hipStreamSynchronize(c->stream));       // a launch in flight may still read the old spans (launches return synchronised, so this is a formality)
+                CK(c, hipMemcpy(c->d_row_spans, spans.data(), (size_t)p->height * sizeof(uint2), hipMemcpyHostToDevice));
+            }
+            c->spans_key = key;
+        }
+        if (c->spans_key.back() == 1.0f) a.row_spans = c->d_row_spans;
     }
     a.queue_heads = c->d_queue;
     a.counters = c->d_counters;
@@ -1002,6 +1122,14 @@ PT_API int pt_debug_queue_order(pt_ctx* c, int mode)
     if (!c || mode < 0 || mode > 5) return fail(c, "pt_debug_queue_order: 0 = contiguous eighths of the tile order per shard; round robin over the shards in units of 1 = a tile-strip row, 2 = a tile, 3 / 4 = two / four rows");
     c->queue_order = mode;
     if (c->multi) for (size_t i = 1; i < c->multi->ranks.size(); i++) c->multi->ranks[i]->queue_order = mode;
+    return 0;
+}
+
+PT_API int pt_debug_pixel_classes(pt_ctx* c, int on)
+{
+    if (!c) return fail(c, "pt_debug_pixel_classes: null context");
+    c->pixel_classes = on ? 1 : 0;
+    if (c->multi) for (size_t i = 1; i < c->multi->ranks.size(); i++) c->multi->ranks[i]->pixel_classes = c->pixel_classes;
     return 0;
 }
 

@@ -53,7 +53,8 @@ struct QueueState {
     uint32_t shard, shards_left, res_first, res_count;
     uint32_t grant_g0;                    // first group of the current grant
     uint32_t free_top;                    // entries on the wave's stack of free fold slots (WaveBook::free)
-    uint32_t grp_pxy, grp_seed;           // PER LANE: lane j holds pixel (x | y << 16, 0xFFFFFFFF = padding) and tea<4> seed of group grant_g0 + j
+    uint32_t grp_pxy, grp_seed;           // PER LANE: lane j holds pixel (x | y << 16, bit 31: every ray of the pixel reaches the scene box; 0xFFFFFFFF = padding) and tea<4> seed of group grant_g0 + j
+    uint32_t skipped;                     // groups of pixels that cannot reach the scene box, settled when their grant was decoded (the kernel books their samples)
 };
 
 struct LanePixel {
@@ -85,6 +86,22 @@ __device__ __forceinline__ void sample_pixel_fast(const RenderArgs& A, uint32_t 
     const uint32_t tile_offset_x = (a - fast_div(a, A.div_world) * world) * 8u;
     py = tile_strip_y * 4u + (tile_pixel_idx >> 3);
     px = tile_strip_x * (8u * world) + (tile_pixel_idx & 7u) + tile_offset_x;
+}
+
+// the sum of one (pixel, sub-frame) is complete: it is parked per (pixel, sub-frame); k_finalize blends the sub-frames of
+// the launch into the accumulation buffer in frame order and applies make_color (the megakernel carries neither: their
+// powf code would be inlined at every place a lane can finish)
+// The sums are indexed by the pixel's slot in this rank's tile order (the inverse of sample_pixel_fast), so a rank that
+// holds 1/world of the tiles holds 1/world of the sums.
+__device__ __forceinline__ uint32_t pixel_slot(const RenderArgs& A, uint32_t pxy)
+{
+    const uint32_t px = pxy & 0xFFFFu, py = pxy >> 16;
+    const uint32_t strip_x = fast_div(px >> 3, A.div_world);              // px / (8 * world)
+    return (((py >> 2) * A.strip_cols + strip_x) << 5) | ((py & 3u) << 3) | (px & 7u);
+}
+__device__ __forceinline__ void write_frame_sum(const RenderArgs& A, uint32_t pxy, uint32_t f, const f3& sum)
+{
+    A.frame_sums[(size_t)pixel_slot(A, pxy) * A.n_frames + f] = make_float4(sum.x, sum.y, sum.z, 0.0f);
 }
 
 // Queue position of a pixel slot -> the pixel slot it stands for.  The queue is cut into eight contiguous shards, one per XCD;
@@ -119,8 +136,10 @@ __device__ __forceinline__ uint32_t queue_slot(const RenderArgs& A, uint32_t pos
 
 // lcg_skip: {multiplier, increment} of the LCG skip-ahead per run, staged in LDS by the kernel (a per-lane table look-up
 // in the kernel-argument segment would be a global load on the deal's critical path)
-template <bool STATS = false>
-__device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q, uint32_t lane, unsigned long long below, LanePixel& lp,
+// late(): the launch constants again, for the grant decode — once per 256 items, so they are read there (kernel-argument segment,
+// scalar cache) instead of being held in scalar registers across the whole persistent kernel (see RenderArgsBox below)
+template <bool STATS = false, typename Late>
+__device__ __forceinline__ void refill_lanes(const RenderArgs& A, Late late, QueueState& q, uint32_t lane, unsigned long long below, LanePixel& lp,
                                              const uint32_t* lcg_skip, const WaveBook& book)
 {
     const uint32_t cs = A.chunk_shift, run_mask = (1u << cs) - 1u;
@@ -128,22 +147,23 @@ __device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q,
     unsigned long long idle = vote(!lp.alive);
     while (idle != 0ull && (q.res_count != 0u || q.shards_left != 0u)) {
         if (q.res_count == 0u) {                                      // wave-uniform: fetch a grant
+            const RenderArgs& G = late();
             const uint32_t leader = (uint32_t)__ffsll((long long)idle) - 1u;
             const uint32_t idle_n = (uint32_t)popc(idle);
-            uint32_t req = idle_n > A.grant ? idle_n : A.grant;       // at least what is needed now,
+            uint32_t req = idle_n > G.grant ? idle_n : G.grant;       // at least what is needed now,
             req = (req + run_mask) & ~run_mask;                       // in whole groups (shards begin on group boundaries)
             uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&A.queue_heads[q.shard], req);
+            if (lane == leader) base = atomicAdd(&G.queue_heads[q.shard], req);
             base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
-            if (STATS && lane == leader && base < A.shard_size) {       // progress of the shard: first grant past each 1/256
-                const uint32_t slot = (uint32_t)(((unsigned long long)base << 8) / A.shard_size);
-                unsigned long long* pr = A.counters + 8 + 3 * kMaxTimedWaves + 256u * q.shard + slot;
+            if (STATS && lane == leader && base < G.shard_size) {       // progress of the shard: first grant past each 1/256
+                const uint32_t slot = (uint32_t)(((unsigned long long)base << 8) / G.shard_size);
+                unsigned long long* pr = G.counters + 8 + 3 * kMaxTimedWaves + 256u * q.shard + slot;
                 if (*pr == 0ull) *pr = __builtin_amdgcn_s_memrealtime();
             }
-            const uint32_t shard_begin = q.shard * A.shard_size;
-            uint32_t shard_end = shard_begin + A.shard_size;
-            if (shard_end > A.total_samples) shard_end = A.total_samples;
-            if (shard_begin > A.total_samples) shard_end = shard_begin;
+            const uint32_t shard_begin = q.shard * G.shard_size;
+            uint32_t shard_end = shard_begin + G.shard_size;
+            if (shard_end > G.total_samples) shard_end = G.total_samples;
+            if (shard_begin > G.total_samples) shard_end = shard_begin;
             const uint32_t first = shard_begin + base;
             uint32_t avail = first < shard_end ? shard_end - first : 0u;
             if (avail > req) avail = req;
@@ -156,11 +176,24 @@ __device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q,
                 q.grant_g0 = first >> cs;
                 const uint32_t g = q.grant_g0 + lane;
                 uint32_t x, y;
-                sample_pixel_fast(A, queue_slot(A, g >> fshift), x, y);
+                sample_pixel_fast(G, queue_slot(G, g >> fshift), x, y);
                 const uint32_t f = g & fmask;
-                const bool ok = (g << cs) < first + avail && x < A.width && y < A.height && f < A.n_frames;   // else: padding of the tile / batch grid
-                q.grp_pxy = ok ? (x | (y << 16)) : 0xFFFFFFFFu;
-                q.grp_seed = tea4(y * A.width + x, A.frame + f);
+                const bool ok = (g << cs) < first + avail && x < G.width && y < G.height && f < G.n_frames;   // else: padding of the tile / batch grid
+                q.grp_seed = tea4(y * G.width + x, G.frame + f);
+                uint32_t pxy = ok ? (x | (y << 16)) : 0xFFFFFFFFu;
+                if (G.row_spans != nullptr) {
+                    // the pixel's class (capi.hip row_spans).  Outside the row's outer span no ray through the pixel reaches the scene's
+                    // bounding box: all its samples are the reference's __miss__ms case (:833-847), their sum is zero — written here, the
+                    // group never becomes work items.  Inside the inner span every ray reaches the box (bit 31): path starts skip the cull test.
+                    const uint2 sp = G.row_spans[ok ? (pxy >> 16) : 0u];
+                    const uint32_t px = pxy & 0xFFFFu;
+                    const bool outside = ok && (px < (sp.x & 0xFFFFu) || px >= (sp.x >> 16));
+                    if (outside) write_frame_sum(G, pxy, f, mk(0.0f));
+                    q.skipped += (uint32_t)popc(vote(outside));
+                    if (ok && px >= (sp.y & 0xFFFFu) && px < (sp.y >> 16)) pxy |= 0x80000000u;
+                    if (outside) pxy = 0xFFFFFFFFu;
+                }
+                q.grp_pxy = pxy;
             }
         }
         const uint32_t want = (uint32_t)popc(idle);
@@ -173,9 +206,10 @@ __device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q,
             const uint32_t run = item & run_mask;
             const uint32_t gj = (item >> cs) - q.grant_g0;
             const int src = (int)(gj << 2);                                    // ds_bpermute takes a byte index
-            const uint32_t pxy = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)q.grp_pxy);
+            const uint32_t pxy_f = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)q.grp_pxy);
             const uint32_t seed0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)q.grp_seed);
-            const bool mine = !lp.alive && rank < take && pxy != 0xFFFFFFFFu;
+            const bool mine = !lp.alive && rank < take && pxy_f != 0xFFFFFFFFu;
+            const uint32_t pxy = pxy_f & 0x7FFFFFFFu;
             uint32_t sl = kNoSlot;
             if (cs != 0u) {
                 // fold slot of the group: the lane that gets run 0 pops one (the n-th such lane of this deal the n-th entry from
@@ -190,7 +224,7 @@ __device__ __forceinline__ void refill_lanes(const RenderArgs& A, QueueState& q,
             }
             if (mine) {
                 lp.pxy = pxy;
-                lp.tag = (((item >> cs) & fmask) << cs) | run | (sl << 16);
+                lp.tag = (((item >> cs) & fmask) << cs) | run | (sl << 16) | ((pxy_f >> 31) << 24);      // bit 24: no cull test needed
                 lp.seed = lcg_skip[2u * run] * seed0 + lcg_skip[2u * run + 1u];     // skip the jitter draws of the samples before this run (2 per sample)
                 lp.result = mk(0.0f);
                 lp.samples_left = A.chunk_spp;
@@ -212,22 +246,6 @@ __device__ __forceinline__ f3 blend_frame(const f3& prev, const f3& result, uint
         accum = lerp3(prev, accum, a);
     }
     return accum;
-}
-
-// the sum of one (pixel, sub-frame) is complete: it is parked per (pixel, sub-frame); k_finalize blends the sub-frames of
-// the launch into the accumulation buffer in frame order and applies make_color (the megakernel carries neither: their
-// powf code would be inlined at every place a lane can finish)
-// The sums are indexed by the pixel's slot in this rank's tile order (the inverse of sample_pixel_fast), so a rank that
-// holds 1/world of the tiles holds 1/world of the sums.
-__device__ __forceinline__ uint32_t pixel_slot(const RenderArgs& A, uint32_t pxy)
-{
-    const uint32_t px = pxy & 0xFFFFu, py = pxy >> 16;
-    const uint32_t strip_x = fast_div(px >> 3, A.div_world);              // px / (8 * world)
-    return (((py >> 2) * A.strip_cols + strip_x) << 5) | ((py & 3u) << 3) | (px & 7u);
-}
-__device__ __forceinline__ void write_frame_sum(const RenderArgs& A, uint32_t pxy, uint32_t f, const f3& sum)
-{
-    A.frame_sums[(size_t)pixel_slot(A, pxy) * A.n_frames + f] = make_float4(sum.x, sum.y, sum.z, 0.0f);
 }
 
 // Two / four consecutive 16-byte loads served by the L2 (sc0: past this CU's L1, whatever an earlier use of the addresses
@@ -258,7 +276,7 @@ __device__ __forceinline__ void finish_runs(const RenderArgs& A, QueueState& q, 
         if (finished) write_frame_sum(A, lp.pxy, sub, lp.result);
         return;
     }
-    const uint32_t slot = lp.tag >> 16;
+    const uint32_t slot = (lp.tag >> 16) & 0xFFu;
     float* group = scratch + 3u * ((size_t)slot << cs);
     bool folder = false;
     if (finished) {

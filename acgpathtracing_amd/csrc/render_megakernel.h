@@ -68,6 +68,9 @@ struct RenderArgs {
     uint32_t  strip_cols;      // tile-strip columns of StaticWorkDistribution for (width, world)
     FastDiv   div_cols, div_world;
     pt_float3 cull_lo, cull_hi;   // scene bounding box, enlarged: a camera ray that misses it ends its path without a traversal
+    // pixel classes (capi.hip row_spans): per image row {x range outside which no ray of a pixel can reach the scene's bounding box,
+    // x range inside which every ray of a pixel does}, two uint32 of two 16-bit columns each; null = unknown (every path start tests)
+    const uint2* row_spans;
     uint32_t  row_interleave;     // 1 (experiment, pt_debug_queue_order): queue position -> tile-strip row 0, 8, 16, ..., 1, 9, ... so that every
     uint32_t  strip_rows;         // queue shard (one per XCD) holds rows from all over the image instead of a contiguous eighth
 };

@@ -72,8 +72,8 @@ k_render(const RenderArgsBox B)
     const float fw = (float)(int)A.width, fh = (float)(int)A.height;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-    QueueState q; q.shard = A.row_interleave == 5u ? 0u : xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.grant_g0 = 0; q.grp_pxy = 0xFFFFFFFFu; q.grp_seed = 0; q.free_top = kFoldSlots;
-    unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0;
+    QueueState q; q.shard = A.row_interleave == 5u ? 0u : xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.grant_g0 = 0; q.grp_pxy = 0xFFFFFFFFu; q.grp_seed = 0; q.skipped = 0; q.free_top = kFoldSlots;
+    unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0, n_culled = 0;
     float* const scratch = A.wave_scratch + 3u * (size_t)(blockIdx.x * (kRenderThreads / 64) + wave) * ((size_t)kFoldSlots << A.chunk_shift);
 
     LanePixel lp; lp.alive = false; lp.new_path = false; lp.pxy = lp.seed = lp.samples_left = lp.tag = 0; lp.result = mk(0.0f);
@@ -82,7 +82,13 @@ k_render(const RenderArgsBox B)
     f3 org = mk(0.0f), dir = mk(0.0f, 0.0f, 1.0f), att = mk(1.0f);
 
     for (;;) {
-        refill_lanes(A, q, lane, below, lp, lcg_skip, book);
+        refill_lanes(A, late, q, lane, below, lp, lcg_skip, book);
+        if (q.skipped != 0u) {
+            const unsigned long long n = (unsigned long long)q.skipped * A.spp;
+            n_radiance += n; n_paths += n; n_culled += n;
+            n_pixels += (unsigned long long)q.skipped << A.chunk_shift;
+            q.skipped = 0u;
+        }
         const unsigned long long live = vote(lp.alive);
         if (live == 0ull) { if (q.shards_left == 0u && q.res_count == 0u) break; else continue; }
 
@@ -144,6 +150,7 @@ k_render(const RenderArgsBox B)
         atomicAdd(&A.counters[1], n_shadow);
         atomicAdd(&A.counters[2], n_paths);
         atomicAdd(&A.counters[3], n_pixels);
+        if (n_culled) atomicAdd(&A.counters[kCulledCounter], n_culled);
     }
 }
 
@@ -279,8 +286,8 @@ k_render_pw(const RenderArgsBox B)
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int root = sc.n_tris ? ((TOPN > 0 && NODE_FMT == 9) ? (int)kTopNodeFlag : 0) : kSentinel;
 
-    QueueState q; q.shard = A.row_interleave == 5u ? 0u : xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.grant_g0 = 0; q.grp_pxy = 0xFFFFFFFFu; q.grp_seed = 0; q.free_top = kFoldSlots;
-    float* const scratch = A.wave_scratch + 3u * (size_t)(blockIdx.x * (THREADS / 64) + wave) * ((size_t)kFoldSlots << A.chunk_shift);
+    QueueState q; q.shard = A.row_interleave == 5u ? 0u : xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.grant_g0 = 0; q.grp_pxy = 0xFFFFFFFFu; q.grp_seed = 0; q.skipped = 0; q.free_top = kFoldSlots;
+    float* const scratch = A.wave_scratch + 3u * (size_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (THREADS / 64) + wave)) * ((size_t)kFoldSlots << A.chunk_shift);   // wave-uniform: scalar registers
     unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0, n_culled = 0;
     unsigned long long n_steps = 0, n_lane_steps = 0, n_rounds = 0, n_lane_rounds = 0;
     // STATS only: 100 MHz stamps of this wave's start, of the moment it found the queue empty, and of its end
@@ -302,8 +309,12 @@ k_render_pw(const RenderArgsBox B)
     bool shadow_ray = false, shadow_hit = false;
     float prev_pdf = 0.0f;                            // LIGHTS (light mode 1) only: pdf of the last sampled direction where a light sample was taken
     bool fin_pending = false;                         // ran out of samples inside the camera cull: its run is finished at the next round's start
-    // held while the shadow ray is in flight
-    Pending pd; pd.nxt_org = mk(0.0f); pd.nxt_dir = mk(0.0f, 0.0f, 1.0f); pd.radiance = mk(0.0f); pd.weight = 0.0f; pd.done = true;
+    // What the closest-hit left for after the shadow ray (Pending), held while that ray is in flight.  Light mode 0 keeps four values
+    // instead of ten: the next bounce's direction (or, for a path that ends on an emitter, the emitter's Ke, which the light
+    // sample is added to, :992-1000, 1015-1024) and the light sample's weight; the next bounce's origin is the shadow ray's own
+    // origin P (diffuse) or P + R * 1e-4 (conductor, :948) and is recomputed with the closest-hit's operations.
+    Pending pd_lights; pd_lights.nxt_org = mk(0.0f); pd_lights.nxt_dir = mk(0.0f, 0.0f, 1.0f); pd_lights.radiance = mk(0.0f); pd_lights.weight = 0.0f; pd_lights.done = true;   // LIGHTS only: the whole record
+    f3 keep_dir = mk(0.0f, 0.0f, 1.0f); float keep_weight = 0.0f; bool keep_done = true, keep_metal = false;
 
     for (;;) {
         // =========================== shade / regenerate: lanes with no ray in flight ===============
@@ -312,10 +323,19 @@ k_render_pw(const RenderArgsBox B)
         if (STATS) { n_rounds += 1; n_lane_rounds += (unsigned long long)popc(vote(lp.alive && node == kSentinel)); t_phase = __builtin_amdgcn_s_memrealtime(); }
         bool segment_done = false, started_shadow = false;
         f3 emission = mk(0.0f);
+        Pending pd;                                                   // lives within one shade round (light mode 1: carried in pd_lights)
+        if (LIGHTS) pd = pd_lights;
+        else { pd.nxt_org = mk(0.0f); pd.nxt_dir = mk(0.0f, 0.0f, 1.0f); pd.radiance = mk(0.0f); pd.weight = 0.0f; pd.done = true; }
         if (lp.alive && node == kSentinel) {
             if (shadow_ray) {                                         // shadow ray back (:1015-1024)
                 if (LIGHTS) { if (shadow_hit) pd.radiance = mk(0.0f); }                // the light sample parked there counts only unoccluded
-                else if (!shadow_hit) pd.radiance += mk(late().light.emission) * pd.weight;
+                else {
+                    pd.done = keep_done; pd.weight = keep_weight;
+                    pd.nxt_dir = keep_dir;
+                    pd.nxt_org = keep_metal ? ro + keep_dir * 1e-4f : ro;             // ro is the shadow ray's origin P
+                    pd.radiance = keep_done ? keep_dir : mk(0.0f);
+                    if (!shadow_hit) pd.radiance += mk(late().light.emission) * pd.weight;
+                }
                 shadow_ray = false;
                 segment_done = true;
             } else {                                                  // radiance ray back
@@ -329,6 +349,12 @@ k_render_pw(const RenderArgsBox B)
                 }
                 lp.result += emission;                                // :760 (before the radiance term)
                 if (want_shadow) {
+                    if (LIGHTS) pd_lights = pd;
+                    else {
+                        keep_done = pd.done; keep_weight = pd.weight;
+                        keep_dir = pd.done ? pd.radiance : pd.nxt_dir;
+                        keep_metal = !pd.done && !(pd.nxt_org.x == P.x && pd.nxt_org.y == P.y && pd.nxt_org.z == P.z);
+                    }
                     ro = P; rd = L;
                     { const RenderArgs& Rs = late(); setup_ray<NODE_FMT>(ro, rd, Rs.scene.grid, Rs.scene.hspace, rinv, gro); }
                     if (NODE_FMT == 8) rot = axis_rot(rinv);
@@ -366,7 +392,13 @@ k_render_pw(const RenderArgsBox B)
         finish_runs(A, q, below, lp, finished, book, scratch);     // before the refill overwrites the lanes' items
         if (STATS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); t_finish += now - t_mark; t_mark = now; }
 
-        refill_lanes<STATS>(A, q, lane, below, lp, lcg_skip, book);
+        refill_lanes<STATS>(A, late, q, lane, below, lp, lcg_skip, book);
+        if (q.skipped != 0u) {      // pixels that cannot reach the scene box: every sample is one radiance segment that misses, one path
+            const unsigned long long n = (unsigned long long)q.skipped * A.spp;
+            n_radiance += n; n_paths += n; n_culled += n;
+            n_pixels += (unsigned long long)q.skipped << A.chunk_shift;
+            q.skipped = 0u;
+        }
         if (STATS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); t_refill += now - t_mark; t_mark = now; }
         if (STATS && t_drain == 0ull && q.shards_left == 0u && q.res_count == 0u) t_drain = __builtin_amdgcn_s_memrealtime();
 
@@ -385,7 +417,7 @@ k_render_pw(const RenderArgsBox B)
                 D = camera_dir((float)(lp.pxy & 0xFFFFu), (float)(lp.pxy >> 16), jx, jy, fw, fh, camU, camV, camW);
                 // a camera ray that cannot reach the scene box: one radiance segment that misses (:833-847 adds nothing to
                 // the result, done = true); its path ends here and the lane goes on to its next sample
-                if (reaches_scene(D, elo, ehi)) break;
+                if ((lp.tag & (1u << 24)) != 0u || reaches_scene(D, elo, ehi)) break;      // bit 24: every ray of this pixel reaches the box
                 my_culled++;
                 lp.samples_left--;
                 if (lp.samples_left == 0u) { lp.alive = false; fin_pending = true; break; }

@@ -58,6 +58,11 @@ int pt_debug_queue_progress(pt_ctx* ctx, uint64_t* out);
  * 8x4-tile order; 1: tile-strip rows are dealt round-robin over the shards (what sutil/WorkDistribution.h:60-81 does across
  * GPUs).  Same image bits either way. */
 int pt_debug_queue_order(pt_ctx* ctx, int mode);
+/* Pixel classes on (default) / off.  On: per image row, the host hands the kernel the columns outside which no ray of a pixel can
+ * reach the scene's bounding box (those pixels' samples are booked as misses without being started) and the columns inside
+ * which every ray does (their path starts skip the cull test).  Same image bits and the same ray / path counters either way;
+ * pt_stats.culled_rays differs (it counts what was settled without a traversal). */
+int pt_debug_pixel_classes(pt_ctx* ctx, int on);
 /* Diagnostic: after a launch of a wavefront kernel variant (render_wavefront.hip), 17 values summed over the waves of the grid,
  * times in 10 ns ticks: trace waves {total, idle}, shade waves {total, idle, deal time / rounds / records, hit-shading time /
  * rounds / records, accounting time / rounds / records}, trace waves {exchange time / exchanges / records taken in, loop trips}. */

@@ -284,6 +284,37 @@ def test_every_kernel_variant_gives_the_same_bits(full):
     assert tried >= 4
 
 
+def test_queue_order_and_pixel_classes_change_no_bit(diffuse):
+    """How the work queue is dealt over its eight shards (contiguous bands, or rows / tiles / row groups round robin, or one
+    queue) and whether pixels are classified beforehand (pixels whose rays cannot reach the scene box are settled when their
+    grant is decoded; pixels whose rays all reach it skip the cull test) are scheduling matters: the accumulation, the
+    framebuffer and the ray / path counters are the same bit for bit.  A 16:9 frame, so that both pixel classes and a band of
+    unclassified pixels around the box's silhouette exist; sample runs on, two frames in one launch."""
+    state, obj, _ = diffuse
+    L = _native.hip()
+    p = make_params(640, 360, 16, 6, True, True)
+    ref = None
+    try:
+        assert L.pt_set_sample_chunks(state.context, 4) == 0
+        for classes, order in ((0, 0), (1, 0), (0, 1), (1, 1), (1, 2), (1, 3), (1, 4), (1, 5)):
+            assert L.pt_debug_pixel_classes(state.context, classes) == 0 and L.pt_debug_queue_order(state.context, order) == 0
+            acc, fb, st = _gpu_render(state, p, frames=2, fuse=2)
+            cnt = (int(st[0].radiance_rays), int(st[0].shadow_rays), int(st[0].paths), int(st[0].pixels))
+            if ref is None:
+                ref = (acc, fb, cnt, int(st[0].culled_rays))
+                assert cnt[2] == 640 * 360 * 16 * 2 and cnt[3] == 640 * 360
+                assert 0.40 < ref[3] / cnt[2] < 0.50          # the box fills the middle of the wide frame
+            else:
+                assert np.array_equal(acc.view(np.uint32), ref[0].view(np.uint32)), (classes, order)
+                assert np.array_equal(fb, ref[1]) and cnt == ref[2], (classes, order)
+                if classes:        # whole pixels settled without a cull test: never fewer than the per-ray test finds
+                    assert int(st[0].culled_rays) >= ref[3] - 16 * 2 * 4 * 360
+        assert L.pt_debug_queue_order(state.context, 6) != 0
+    finally:
+        L.pt_debug_pixel_classes(state.context, 1); L.pt_debug_queue_order(state.context, 1)
+        L.pt_set_sample_chunks(state.context, 1)
+
+
 def test_fast_math_variant(full):
     """Kernel variant 10 (opt-in): hardware sin / cos and an algebraic sin(acos(.)) in the cosine-weighted sampler, as
     the reference's --use_fast_math build would use.  Not bit-identical to the default, but the same image within the

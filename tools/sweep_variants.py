@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--partition", default="0,1", help="rank,world pixel-tile partition")
     ap.add_argument("--build-mode", type=int, default=None, help="0 Karras LBVH, 1 PLOC (library default)")
     ap.add_argument("--fuse", type=int, default=1, help="sub-frames per kernel launch (pt_launch_frames)")
+    ap.add_argument("--pixel-classes", type=int, default=1, help="0: every path start tests its camera ray against the scene box (pt_debug_pixel_classes)")
     ap.add_argument("--queue-order", type=int, default=1, help="1: tile-strip rows interleaved over the queue shards (pt_debug_queue_order)")
     a = ap.parse_args()
     L = _native.hip()
@@ -44,6 +45,7 @@ def main():
     rank, world = [int(x) for x in a.partition.split(",")]
     assert L.pt_set_partition(state.context, rank, world) == 0
     assert L.pt_debug_queue_order(state.context, a.queue_order) == 0
+    assert L.pt_debug_pixel_classes(state.context, a.pixel_classes) == 0
     info = pt.getBvhInfo(state)
     print("scene %s: %d tris, depth %d, stack %d, build %.2f ms" % (a.scene, info.n_tris, info.max_depth, info.stack_entries, info.build_ms))
     variants = list(range(64)) if a.variants == "all" else [int(v) for v in a.variants.split(",")]
