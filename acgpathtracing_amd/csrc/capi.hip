@@ -1119,7 +1119,7 @@ PT_API int pt_debug_queue_progress(pt_ctx* c, uint64_t* out)
 
 PT_API int pt_debug_queue_order(pt_ctx* c, int mode)
 {
-    if (!c || mode < 0 || mode > 5) return fail(c, "pt_debug_queue_order: 0 = contiguous eighths of the tile order per shard; round robin over the shards in units of 1 = a tile-strip row, 2 = a tile, 3 / 4 = two / four rows");
+    if (!c || mode < 0 || mode > 3) return fail(c, "pt_debug_queue_order: 0 = contiguous eighths of the tile order per shard; round robin over the shards in units of 1 = a tile-strip row (default), 2 = a tile; 3 = one queue in image order");
     c->queue_order = mode;
     if (c->multi) for (size_t i = 1; i < c->multi->ranks.size(); i++) c->multi->ranks[i]->queue_order = mode;
     return 0;
@@ -1138,6 +1138,7 @@ PT_API int pt_debug_wf(pt_ctx* c, uint64_t* out)
     if (!c || !out) return fail(c, "pt_debug_wf: null argument");
     CK(c, hipSetDevice(c->device));
     CK(c, hipMemcpy(out, c->d_counters + ptd::kWfDiag, 17 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    CK(c, hipMemcpy(out + 17, c->d_counters + ptd::kWindowMoves, sizeof(uint64_t), hipMemcpyDeviceToHost));
     return 0;
 }
 

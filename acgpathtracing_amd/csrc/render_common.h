@@ -107,24 +107,18 @@ __device__ __forceinline__ void write_frame_sum(const RenderArgs& A, uint32_t px
 // Queue position of a pixel slot -> the pixel slot it stands for.  The queue is cut into eight contiguous shards, one per XCD;
 // with the identity (A.row_interleave 0) a shard is a contiguous band of the image, and bands differ in cost: XCDs drift apart
 // by up to a fifth of the launch and even out only by stealing at the end (profiles/r02_wave_timeline.txt).  Otherwise the
-// image is dealt in units — 1: a tile-strip row (4 pixel rows), 2: one 8x4 tile, 3 / 4: two / four tile-strip rows — and the
-// units go to the shards round robin (unit u to shard u mod 8, what sutil/WorkDistribution.h:60-81 does across GPUs): queue
-// order = units 0, 8, 16, ..., 1, 9, 17, ...
+// image is dealt in units — 1: a tile-strip row (4 pixel rows), 2: one 8x4 tile — and the units go to the shards round robin
+// (unit u to shard u mod 8, what sutil/WorkDistribution.h:60-81 does across GPUs): queue order = units 0, 8, 16, ..., 1, 9, ...
+// (All units are the same size, so this is a permutation of the pixel slots.)  3: the identity, with every wave starting at
+// shard 0 — one queue in image order.
 __device__ __forceinline__ uint32_t queue_slot(const RenderArgs& A, uint32_t pos)
 {
     const uint32_t mode = A.row_interleave;
-    if (mode == 0u || mode == 5u) return pos;          // 5 (experiment): identity, and every wave starts at shard 0: one queue in image order
+    if (mode != 1u && mode != 2u) return pos;
     const uint32_t tile = pos >> 5;
     uint32_t k, within, unit_tiles, n_units;           // unit position in queue order, tile within the unit
     if (mode == 2u) { k = tile; within = 0u; unit_tiles = 1u; n_units = A.strip_rows * A.strip_cols; }
-    else {
-        const uint32_t sh = mode == 1u ? 0u : (mode == 3u ? 1u : 2u);
-        const uint32_t row = fast_div(tile, A.div_cols);
-        k = row >> sh;
-        unit_tiles = A.strip_cols << sh;
-        within = tile - k * unit_tiles;
-        n_units = (A.strip_rows + (1u << sh) - 1u) >> sh;
-    }
+    else { k = fast_div(tile, A.div_cols); unit_tiles = A.strip_cols; within = tile - k * unit_tiles; n_units = A.strip_rows; }
     uint32_t unit = k;
     for (uint32_t s = 0; s < 8u; s++) {
         const uint32_t n_s = n_units > s ? (n_units - s + 7u) >> 3 : 0u;     // units congruent to s modulo 8

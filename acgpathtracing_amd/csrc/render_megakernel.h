@@ -12,6 +12,7 @@ constexpr uint32_t kMaxTimedWaves = 16384;   // stats variants stamp start / que
 // then 2056 words of queue progress and phase times (stats variants), then kTailCounters more launch counters
 constexpr uint32_t kCulledCounter = 8u + 3u * kMaxTimedWaves + 2056u;   // camera rays ended by the scene-box cull (they are part of counters[0] and [2] too)
 constexpr uint32_t kAbortCounter = kCulledCounter + 1u;                 // workgroups of a wavefront kernel that gave up (scheduling error or watchdog): the launch fails
+constexpr uint32_t kWindowMoves = kCulledCounter + 20u;  // wave-level moves of stack entries between the LDS window and global memory (windowed-stack kernels)
 constexpr uint32_t kWfDiag = kCulledCounter + 2u;      // 12 words of wavefront-kernel diagnostics (render_wavefront.hip, pt_debug_wf)
 constexpr uint32_t kTailCounters = 24u;
 constexpr uint32_t kCounterWords = kCulledCounter + kTailCounters;

@@ -72,7 +72,7 @@ k_render(const RenderArgsBox B)
     const float fw = (float)(int)A.width, fh = (float)(int)A.height;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
-    QueueState q; q.shard = A.row_interleave == 5u ? 0u : xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.grant_g0 = 0; q.grp_pxy = 0xFFFFFFFFu; q.grp_seed = 0; q.skipped = 0; q.free_top = kFoldSlots;
+    QueueState q; q.shard = A.row_interleave == 3u ? 0u : xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.grant_g0 = 0; q.grp_pxy = 0xFFFFFFFFu; q.grp_seed = 0; q.skipped = 0; q.free_top = kFoldSlots;
     unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0, n_culled = 0;
     float* const scratch = A.wave_scratch + 3u * (size_t)(blockIdx.x * (kRenderThreads / 64) + wave) * ((size_t)kFoldSlots << A.chunk_shift);
 
@@ -286,10 +286,11 @@ k_render_pw(const RenderArgsBox B)
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int root = sc.n_tris ? ((TOPN > 0 && NODE_FMT == 9) ? (int)kTopNodeFlag : 0) : kSentinel;
 
-    QueueState q; q.shard = A.row_interleave == 5u ? 0u : xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.grant_g0 = 0; q.grp_pxy = 0xFFFFFFFFu; q.grp_seed = 0; q.skipped = 0; q.free_top = kFoldSlots;
+    QueueState q; q.shard = A.row_interleave == 3u ? 0u : xcc_id(); q.shards_left = 8; q.res_first = 0; q.res_count = 0; q.grant_g0 = 0; q.grp_pxy = 0xFFFFFFFFu; q.grp_seed = 0; q.skipped = 0; q.free_top = kFoldSlots;
     float* const scratch = A.wave_scratch + 3u * (size_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (THREADS / 64) + wave)) * ((size_t)kFoldSlots << A.chunk_shift);   // wave-uniform: scalar registers
     unsigned long long n_radiance = 0, n_shadow = 0, n_paths = 0, n_pixels = 0, n_culled = 0;
     unsigned long long n_steps = 0, n_lane_steps = 0, n_rounds = 0, n_lane_rounds = 0;
+    uint32_t n_moves = 0;                             // WINDOW: times this wave moved stack entries out of / back into the LDS window
     // STATS only: 100 MHz stamps of this wave's start, of the moment it found the queue empty, and of its end
     unsigned long long t_start = 0, t_drain = 0, t_phase = 0, t_in_shade = 0, t_refill = 0, t_finish = 0, t_newpath = 0, t_mark = 0;
     if (STATS) { t_start = __builtin_amdgcn_s_memrealtime(); t_phase = t_start; }
@@ -510,6 +511,7 @@ k_render_pw(const RenderArgsBox B)
                     const bool out = act && sp + TRIP > wbase + WIN;
                     const bool in = act && wbase > 0 && sp - (TRIP + LEAVES) < wbase;
                     if (vote(out || in) == 0ull) break;
+                    n_moves += 1u;
                     if (out) {
 #pragma unroll
                         for (int j = 0; j < 4; j++) ovf[(uint32_t)(wbase + j) * 64u + lane] = (uint32_t)st.pop((wbase + j) & (WIN - 1));
@@ -740,6 +742,7 @@ k_render_pw(const RenderArgsBox B)
         atomicAdd(&A.counters[6], n_rounds);
         atomicAdd(&A.counters[7], n_lane_rounds);
         if (n_culled) atomicAdd(&A.counters[kCulledCounter], n_culled);
+        if (WINDOW && n_moves) atomicAdd(&A.counters[kWindowMoves], (unsigned long long)n_moves);
         if (STATS) {
             const uint32_t w = blockIdx.x * (THREADS / 64) + wave;
             if (w < kMaxTimedWaves) {

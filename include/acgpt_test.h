@@ -54,16 +54,17 @@ int pt_debug_wave_times(pt_ctx* ctx, uint64_t* out, size_t max_waves);
  * 8 * 256 values (0 = never reached by a stamped grant), followed by ONE value: the time all waves together spent
  * in the shade / regenerate phase, in 10 ns units and its split into queue refill / finished runs / camera-path start (2056 values in all: 2048 + 1 + 3, rest unused). */
 int pt_debug_queue_progress(pt_ctx* ctx, uint64_t* out);
-/* Experiment: order of the work queue.  0 (default): each of the eight queue shards (one per XCD) is a contiguous eighth of the
- * 8x4-tile order; 1: tile-strip rows are dealt round-robin over the shards (what sutil/WorkDistribution.h:60-81 does across
- * GPUs).  Same image bits either way. */
+/* Order of the work queue over its eight shards (one per XCD).  0: each shard is a contiguous eighth of the 8x4-tile order
+ * (round 2); 1 (default): tile-strip rows are dealt round robin over the shards (what sutil/WorkDistribution.h:60-81 does
+ * across GPUs); 2: single tiles round robin; 3: one queue in image order.  Same image bits and counters in every mode. */
 int pt_debug_queue_order(pt_ctx* ctx, int mode);
 /* Pixel classes on (default) / off.  On: per image row, the host hands the kernel the columns outside which no ray of a pixel can
  * reach the scene's bounding box (those pixels' samples are booked as misses without being started) and the columns inside
  * which every ray does (their path starts skip the cull test).  Same image bits and the same ray / path counters either way;
  * pt_stats.culled_rays differs (it counts what was settled without a traversal). */
 int pt_debug_pixel_classes(pt_ctx* ctx, int on);
-/* Diagnostic: after a launch of a wavefront kernel variant (render_wavefront.hip), 17 values summed over the waves of the grid,
+/* Diagnostic: 18 values of the last launch.  [17]: a windowed-stack kernel's moves of stack entries between the LDS window and
+ * global memory (wave-level events).  [0..16]: after a launch of a wavefront kernel variant (render_wavefront.hip), summed over the waves of the grid,
  * times in 10 ns ticks: trace waves {total, idle}, shade waves {total, idle, deal time / rounds / records, hit-shading time /
  * rounds / records, accounting time / rounds / records}, trace waves {exchange time / exchanges / records taken in, loop trips}. */
 int pt_debug_wf(pt_ctx* ctx, uint64_t* out);

@@ -285,8 +285,7 @@ def test_every_kernel_variant_gives_the_same_bits(full):
 
 
 def test_queue_order_and_pixel_classes_change_no_bit(diffuse):
-    """How the work queue is dealt over its eight shards (contiguous bands, or rows / tiles / row groups round robin, or one
-    queue) and whether pixels are classified beforehand (pixels whose rays cannot reach the scene box are settled when their
+    """How the work queue is dealt over its eight shards (contiguous bands, rows or tiles round robin, or one queue) and whether pixels are classified beforehand (pixels whose rays cannot reach the scene box are settled when their
     grant is decoded; pixels whose rays all reach it skip the cull test) are scheduling matters: the accumulation, the
     framebuffer and the ray / path counters are the same bit for bit.  A 16:9 frame, so that both pixel classes and a band of
     unclassified pixels around the box's silhouette exist; sample runs on, two frames in one launch."""
@@ -296,7 +295,7 @@ def test_queue_order_and_pixel_classes_change_no_bit(diffuse):
     ref = None
     try:
         assert L.pt_set_sample_chunks(state.context, 4) == 0
-        for classes, order in ((0, 0), (1, 0), (0, 1), (1, 1), (1, 2), (1, 3), (1, 4), (1, 5)):
+        for classes, order in ((0, 0), (1, 0), (0, 1), (1, 1), (1, 2), (1, 3)):
             assert L.pt_debug_pixel_classes(state.context, classes) == 0 and L.pt_debug_queue_order(state.context, order) == 0
             acc, fb, st = _gpu_render(state, p, frames=2, fuse=2)
             cnt = (int(st[0].radiance_rays), int(st[0].shadow_rays), int(st[0].paths), int(st[0].pixels))
@@ -309,7 +308,7 @@ def test_queue_order_and_pixel_classes_change_no_bit(diffuse):
                 assert np.array_equal(fb, ref[1]) and cnt == ref[2], (classes, order)
                 if classes:        # whole pixels settled without a cull test: never fewer than the per-ray test finds
                     assert int(st[0].culled_rays) >= ref[3] - 16 * 2 * 4 * 360
-        assert L.pt_debug_queue_order(state.context, 6) != 0
+        assert L.pt_debug_queue_order(state.context, 4) != 0
     finally:
         L.pt_debug_pixel_classes(state.context, 1); L.pt_debug_queue_order(state.context, 1)
         L.pt_set_sample_chunks(state.context, 1)
@@ -449,6 +448,61 @@ def test_edge_cases(gpu_state_factory, oracle, tmp_path):
     mats = (pt.Material * 1)()
     assert L.pt_set_scene(state.context, vv.ctypes.data, 3, ii.ctypes.data, 1, mm.ctypes.data, C.addressof(mats), 1) != 0
     assert b"material index" in L.pt_last_error(state.context)
+
+
+def test_windowed_stack_on_a_deep_tree(gpu_state_factory, oracle, tmp_path):
+    """The large-scene kernel keeps a sliding window of 16 stack entries per lane in LDS and moves deeper ones to global memory
+    four at a time.  2^18 small triangles strung along the camera's axis, a little off it: a ray down the axis enters the boxes
+    of both children at every level of an 18-level tree, so its stack of pending far children outgrows the window and shrinks
+    again.  The windowed kernel must move entries (counted), and agree bit for bit with the kernels that keep the whole stack
+    in LDS (fp32 nodes, four waves) and with the segment-synchronous one; and match the oracle."""
+    n = 1 << 18
+    k = np.arange(n, dtype=np.float64)
+    ang = k * 2.399963                               # golden-angle spiral around the axis
+    rad = 0.6 + 1.4 * ((k * 0.6180339887) % 1.0)
+    cx, cy, cz = 278.0 + rad * np.cos(ang), 273.0 + rad * np.sin(ang), 20.0 + 500.0 * k / n
+    v = np.empty((n, 3, 3))
+    v[:, 0] = np.stack([cx, cy, cz], 1)
+    v[:, 1] = np.stack([cx + 0.35, cy + 0.05, cz], 1)
+    v[:, 2] = np.stack([cx + 0.05, cy + 0.35, cz], 1)
+    with open(tmp_path / "line.obj", "w") as fh:
+        fh.write("mtllib line.mtl\nusemtl white\n")
+        np.savetxt(fh, v.reshape(-1, 3), fmt="v %.4f %.4f %.4f")
+        idx = np.arange(1, 3 * n + 1).reshape(n, 3)
+        np.savetxt(fh, idx, fmt="f %d %d %d")
+        fh.write("usemtl light\nv 213 548 227\nv 343 548 227\nv 343 548 332\nv 213 548 332\nf -4 -3 -2 -1\n")
+    (tmp_path / "line.mtl").write_text("newmtl white\nKd 0.7 0.7 0.7\nnewmtl light\nKd 0.8 0.8 0.8\nKe 10 10 10\n")
+    L = _native.hip()
+    state, obj = gpu_state_factory(str(tmp_path / "line.obj"), width=64, height=64)
+    info = pt.getBvhInfo(state)
+    assert info.n_tris == n + 2 and info.stack_entries > 18, info.stack_entries
+    sc = oracle.scene(obj.getVerticesFloat(), obj.getIndexBuffer(), obj.getMaterialIndices(), obj.getMaterials())
+    p = make_params(96, 96, 4, 4, True, True)
+    # a narrow view straight down the string: the image is 4 units wide where the string begins and 9 where it ends
+    p.cameraEye = _native.Float3(278.0, 273.0, -400.0)
+    p.cameraU, p.cameraV, p.cameraW = _native.Float3(-2.0, 0.0, 0.0), _native.Float3(0.0, 2.0, 0.0), _native.Float3(0.0, 0.0, 400.0)
+    ref, _, ref_st, _ = sc.render(copy_params(p), use_bvh=True)
+    imgs, moves = {}, 0
+    try:
+        for v_ in (9, 3, 0):                  # windowed stack / fp32 nodes, whole stack in LDS / segment-synchronous
+            assert L.pt_set_tuning(state.context, 0, v_) == 0, L.pt_last_error(state.context)
+            acc, fb, st = _gpu_render(state, p)
+            assert int(st[0].variant) == v_
+            imgs[v_] = (acc, (int(st[0].radiance_rays), int(st[0].shadow_rays)))
+            if v_ == 9:
+                d = (C.c_uint64 * 18)()
+                assert L.pt_debug_wf(state.context, d) == 0
+                moves = int(d[17])
+    finally:
+        assert L.pt_set_tuning(state.context, 0, _DEFAULT_VARIANT) == 0
+    print("windowed stack: %d wave-level moves between the LDS window and global memory; stack %d entries" % (moves, info.stack_entries))
+    assert moves > 0, "no ray outgrew the window: the test does not exercise what it is for"
+    for v_, (acc, cnt) in imgs.items():
+        assert np.array_equal(acc.view(np.uint32), imgs[0][0].view(np.uint32)), "variant %d differs from the segment-synchronous kernel" % v_
+        assert cnt == imgs[0][1], v_
+    assert image_mse(imgs[9][0], ref) < MSE_TOL
+    assert abs(imgs[9][1][0] - ref_st["radiance_rays"]) <= 2e-3 * ref_st["radiance_rays"]
+    sc.close()
 
 
 def test_large_scene_properties(gpu_state_factory, oracle, tmp_path):

@@ -53,7 +53,7 @@ for chunks in chunk_list:
             ok = ok and same and cnt == ref[1]
         print(line, flush=True)
         if st.variant >= 10:
-            d = (C.c_uint64 * 17)()
+            d = (C.c_uint64 * 18)()
             L.pt_debug_wf(state.context, d)
             d = [int(x) for x in d]
             tt, ti, stt, si = d[0], d[1], d[2], d[3]
