@@ -809,10 +809,10 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
         if (p->samplesPerPixel % (uint32_t)c->chunks != 0u) return fail(c, "pt_launch: samplesPerPixel is not a multiple of the sample-chunk count");
         while ((1 << a.chunk_shift) < c->chunks) a.chunk_shift++;
     } else {
-        // automatic: 8 runs per pixel, 16 / 32 when this rank holds few pixels (shorter items keep the
+        // automatic: 8 runs per pixel, 16 when this rank holds fewer than 2^20 pixels (shorter items keep the
         // tail of the launch short), as long as every run keeps >= 4 samples
         const uint32_t my_pixels = (uint32_t)(((uint64_t)p->width * p->height) / (uint64_t)c->world);
-        uint32_t want = my_pixels < (1u << 19) ? 5u : (my_pixels < (1u << 20) ? 4u : 3u);
+        uint32_t want = my_pixels < (1u << 20) ? 4u : 3u;      // (32 runs below 2^19 pixels until round 3: 22.4 ms for a rank of eight against 22.1 with 16, profiles/r03_sweep_partitions.txt)
         while (want > 0u && (p->samplesPerPixel % (1u << want) != 0u || (p->samplesPerPixel >> want) < 4u)) want--;
         a.chunk_shift = want;
     }

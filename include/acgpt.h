@@ -210,7 +210,7 @@ int pt_resolve_framebuffer(pt_ctx* ctx, const float* accumulation_rgba, uint8_t*
 int pt_set_light_mode(pt_ctx* ctx, int mode);
 
 /* Sample chunks (1, 2, 4, 8, 16, 32; 0 = automatic, the default: 8 runs per pixel, 16 when this rank
- * holds fewer than 2^20 pixels, 32 below 2^19, reduced until every run keeps at least 4 samples).  With c > 1 a pixel's samplesPerPixel samples are cut into
+ * holds fewer than 2^20 pixels, reduced until every run keeps at least 4 samples).  With c > 1 a pixel's samplesPerPixel samples are cut into
  * c consecutive runs, each owned by its own lane with the PRNG skipped ahead to where the run
  * starts, and the runs' partial sums are added in run order.  Same samples, same paths; only the
  * association of the fp32 sum changes ((s1+..+sk) + (sk+1+..) instead of one left-to-right chain), so
