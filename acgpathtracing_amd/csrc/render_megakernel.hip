@@ -1141,24 +1141,24 @@ hipError_t trace_stream_occupancy(int fmt, uint32_t stack_entries, int* blocks_p
 struct VariantDesc { RenderKernel k; int threads; int node_fmt; const char* name; int stack_cap = 0; const char* kernel = ""; int wf = -1; int top_n = 0; };   // wf >= 0: index into render_wavefront.hip's table
 
 // Render kernel variants.  0: segment-synchronous (fp32 nodes).  Others: persistent traversal
-// <SHADE_K, LEAF_K, NODE_FMT, THREADS, MINW, STATS, DIAG, INNER, LEAVES, LIGHTS, STACK_CAP>.  The product library carries the
+// <SHADE_K, LEAF_K, NODE_FMT, THREADS, MINW, STATS, DIAG, INNER, LEAVES, LIGHTS, STACK_CAP, TOPN>.  The product library carries the
 // variants a user can meaningfully pick (indices fixed: render_megakernel.h); everything that was measured on the way and lost is
 // compiled only with -DACGPT_EXPERIMENTS (acgpathtracing_amd/_build.py build_hip(experiments=True), tools/sweep_variants.py).
-// PW(...): the instantiation and its name as a kernel trace prints it (all eleven arguments spelled out), so that a profile
+// PW(...): the instantiation and its name as a kernel trace prints it (all twelve arguments spelled out), so that a profile
 // can be tied to the variant that ran (pt_variant_kernel, bench.py).
 #define PW(...) k_render_pw<__VA_ARGS__>
 #define PWN(...) "k_render_pw<" #__VA_ARGS__ ">"
 static const VariantDesc kVariants[] = {
     {k_render, 256, 0, "sync fp32-nodes", 0, "k_render"},
-    {PW(44, 16, 0, 256, 4, false, 0, 2, 2, false, 0), 256, 0, "pw K44 L16 fp32 nodes w4, register stack top, two visits and two triangle tests per loop trip", 0, PWN(44, 16, 0, 256, 4, false, 0, 2, 2, false, 0)},
-    {PW(44, 16, 0, 256, 4, true, 0, 2, 2, false, 0), 256, 0, "pw K44 L16 fp32 nodes + scheduler stats", 0, PWN(44, 16, 0, 256, 4, true, 0, 2, 2, false, 0)},
-    {PW(48, 8, 0, 256, 4, false, 0, 2, 1, false, 0), 256, 0, "pw K48 L8 fp32 nodes w4, two visits per loop trip (large scenes whose fp16 planes would be too coarse)", 0, PWN(48, 8, 0, 256, 4, false, 0, 2, 1, false, 0)},
-    {PW(48, 12, 0, 256, 4, false, 3, 1, 1, false, 0), 256, 0, "FAST-MATH hardware sin/cos + algebraic acos in the cosine-weighted sampler (opt-in; other bits than the default)", 0, PWN(48, 12, 0, 256, 4, false, 3, 1, 1, false, 0)},
-    {PW(44, 16, 8, 256, 4, false, 0, 3, 2, false, 0), 256, 8, "pw K44 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes, w4, three visits and two triangle tests per loop trip", 0, PWN(44, 16, 8, 256, 4, false, 0, 3, 2, false, 0)},
-    {PW(44, 16, 9, 256, 4, true, 0, 5, 2, false, 0), 256, 9, "pw K44 L16 fp16 sign-rotated nodes, five visits per trip + scheduler stats (the default kernel's loop at four waves)", 0, PWN(44, 16, 9, 256, 4, true, 0, 5, 2, false, 0)},
-    {PW(40, 16, 9, 256, 5, false, 0, 5, 2, false, 0), 256, 9, "pw K40 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes with the rotate amounts in the multipliers' low bits, FIVE waves per SIMD (96 registers), five visits and two triangle tests per loop trip", 0, PWN(40, 16, 9, 256, 5, false, 0, 5, 2, false, 0)},
-    {PW(44, 16, 9, 256, 4, false, 0, 5, 2, true, 0), 256, 9, "LIGHTS scene-driven area lights + MIS (light mode 1, opt-in: not the reference's estimator), fp16 sign-rotated nodes w4", 0, PWN(44, 16, 9, 256, 4, false, 0, 5, 2, true, 0)},
-    {PW(24, 16, 9, 256, 5, false, 0, 5, 2, false, -16), 256, 9, "pw K24 L16 fp16 sign-rotated nodes, five waves per SIMD, for large scenes and deep trees: shade rounds at 24 parked lanes (rays are long there), a sliding window of 16 stack entries per lane in LDS, deeper ones moved to global memory four at a time", -16, PWN(24, 16, 9, 256, 5, false, 0, 5, 2, false, -16)},
+    {PW(44, 16, 0, 256, 4, false, 0, 2, 2, false, 0, 0), 256, 0, "pw K44 L16 fp32 nodes w4, register stack top, two visits and two triangle tests per loop trip", 0, PWN(44, 16, 0, 256, 4, false, 0, 2, 2, false, 0, 0)},
+    {PW(44, 16, 0, 256, 4, true, 0, 2, 2, false, 0, 0), 256, 0, "pw K44 L16 fp32 nodes + scheduler stats", 0, PWN(44, 16, 0, 256, 4, true, 0, 2, 2, false, 0, 0)},
+    {PW(48, 8, 0, 256, 4, false, 0, 2, 1, false, 0, 0), 256, 0, "pw K48 L8 fp32 nodes w4, two visits per loop trip (large scenes whose fp16 planes would be too coarse)", 0, PWN(48, 8, 0, 256, 4, false, 0, 2, 1, false, 0, 0)},
+    {PW(48, 12, 0, 256, 4, false, 3, 1, 1, false, 0, 0), 256, 0, "FAST-MATH hardware sin/cos + algebraic acos in the cosine-weighted sampler (opt-in; other bits than the default)", 0, PWN(48, 12, 0, 256, 4, false, 3, 1, 1, false, 0, 0)},
+    {PW(44, 16, 8, 256, 4, false, 0, 3, 2, false, 0, 0), 256, 8, "pw K44 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes, w4, three visits and two triangle tests per loop trip", 0, PWN(44, 16, 8, 256, 4, false, 0, 3, 2, false, 0, 0)},
+    {PW(44, 16, 9, 256, 4, true, 0, 5, 2, false, 0, 0), 256, 9, "pw K44 L16 fp16 sign-rotated nodes, five visits per trip + scheduler stats (the default kernel's loop at four waves)", 0, PWN(44, 16, 9, 256, 4, true, 0, 5, 2, false, 0, 0)},
+    {PW(40, 16, 9, 256, 5, false, 0, 5, 2, false, 0, 0), 256, 9, "pw K40 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes with the rotate amounts in the multipliers' low bits, FIVE waves per SIMD (96 registers), five visits and two triangle tests per loop trip", 0, PWN(40, 16, 9, 256, 5, false, 0, 5, 2, false, 0, 0)},
+    {PW(44, 16, 9, 256, 4, false, 0, 5, 2, true, 0, 0), 256, 9, "LIGHTS scene-driven area lights + MIS (light mode 1, opt-in: not the reference's estimator), fp16 sign-rotated nodes w4", 0, PWN(44, 16, 9, 256, 4, false, 0, 5, 2, true, 0, 0)},
+    {PW(24, 16, 9, 256, 5, false, 0, 5, 2, false, -16, 0), 256, 9, "pw K24 L16 fp16 sign-rotated nodes, five waves per SIMD, for large scenes and deep trees: shade rounds at 24 parked lanes (rays are long there), a sliding window of 16 stack entries per lane in LDS, deeper ones moved to global memory four at a time", -16, PWN(24, 16, 9, 256, 5, false, 0, 5, 2, false, -16, 0)},
     {nullptr, 0, 9, nullptr, 0, nullptr, 0},      // kVariantWf16: filled from render_wavefront.hip's table (variant_desc)
     {nullptr, 0, 9, nullptr, 0, nullptr, 1},      // kVariantWf10
     {nullptr, 0, 9, nullptr, 0, nullptr, 2},

@@ -99,3 +99,24 @@ def test_render_kernels_keep_their_occupancy_budget(lib):
         assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
     for k, args in four:
         assert k["vgpr_count"] <= 128 and k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
+
+
+def test_variant_kernel_names_are_the_code_objects(lib):
+    """pt_variant_kernel(v) is what bench.py holds a committed profile against: it must be, character for character, the name
+    a kernel trace prints for that variant's instantiation — i.e. a kernel that exists in the built code object."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_meta
+    names = [k["name"] for k in kernel_meta.kernel_table(_native.hip_library_path())]
+    n = 0
+    for v in range(64):
+        if lib.pt_variant_name(v) is None:
+            break
+        kern = lib.pt_variant_kernel(v).decode()
+        assert kern, "variant %d has no kernel name" % v
+        hits = [x for x in names if ("ptd::" + kern + "(") in x]
+        assert len(hits) == 1, (v, kern, [x for x in names if kern.split("<")[0] in x][:3])
+        n += 1
+    assert n >= 10
+    assert re.fullmatch(r"[0-9a-f]{16}", lib.pt_kernel_source_hash().decode())
+    assert lib.pt_kernel_source_hash().decode() == _build.kernel_source_hash()
