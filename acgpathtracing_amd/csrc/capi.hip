@@ -323,6 +323,15 @@ static int size_stack(pt_ctx* c)
 
 // The four-wide tree is built on first use (a kernel variant or diagnostic that walks it): its host-side
 // collapse is not part of the default scene set-up.
+// ... and so is the breadth-first copy of the tree's top, for the variants that stage it in LDS
+static int ensure_top(pt_ctx* c)
+{
+    if (ptd::render_variant_top_nodes(c->variant) == 0) return 0;
+    std::string err;
+    if (!ptd::build_top_nodes(c->bvh, c->stream, err)) return fail(c, err);
+    return 0;
+}
+
 static int ensure_wide(pt_ctx* c)
 {
     if (c->bvh.wrecs || c->bvh.n_tris == 0) return 0;
@@ -386,6 +395,7 @@ static int set_scene_one(pt_ctx* c, const float* verts_xyzw, size_t n_verts, con
     if (int rc = size_stack(c)) return rc;              // stack depth first: the choice below depends on it
     if (c->variant_auto) { c->variant = pick_variant(c); if (int rc = size_stack(c)) return rc; }
     if (ptd::render_variant_node_format(c->variant) == 3) { if (int rc = ensure_wide(c)) return rc; }
+    if (int rc = ensure_top(c)) return rc;
     c->scene_serial++;
     return 0;
 }
@@ -457,6 +467,7 @@ static int set_tuning_one(pt_ctx* c, int blocks_per_cu, int variant)
     c->variant_auto = variant < 0;
     c->variant = variant < 0 ? pick_variant(c) : variant;
     if (ptd::render_variant_node_format(c->variant) == 3) { if (int rc = ensure_wide(c)) return rc; }
+    if (int rc = ensure_top(c)) return rc;
     CK(c, ptd::render_occupancy(c->variant, c->stack_entries, c->bvh.n_nodes, &c->blocks_per_cu));
     if (c->blocks_per_cu < 1) return fail(c, "pt_set_tuning: this kernel variant does not fit the current scene in LDS");
     return 0;

@@ -40,6 +40,9 @@ bool build_lbvh(const float* h_verts_xyzw, size_t n_verts, const uint32_t* h_idx
 
 void free_lbvh(LbvhResult& r);
 
+// The first kTopNodesMax inner nodes breadth first (LbvhResult::top_nodes), on first use (experiment variants only).
+bool build_top_nodes(LbvhResult& r, hipStream_t stream, std::string& err);
+
 // Collapse the two-child tree into the four-wide, 8-bit-quantised record array (wide_bvh.hip).
 bool build_wide4(LbvhResult& r, hipStream_t stream, std::string& err);
 

@@ -733,12 +733,6 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
         k_half_nodes<<<(n_nodes + 255) / 256, 256, 0, stream>>>(out.nodes, n_nodes, sp, out.hnodes, d_area);
         HIPCK(hipGetLastError());
         HIPCK(hipMemcpyAsync(h_area, d_area, 16, hipMemcpyDeviceToHost, stream));
-        uint32_t* d_ntop;
-        HIPCK(sc.alloc(&d_ntop, 4));
-        HIPCK(hipMalloc((void**)&out.top_nodes, (size_t)kTopNodesMax * (sizeof(HNode) + sizeof(uint32_t))));      // nodes, then their indices in hnodes
-        k_top_nodes<<<1, 64, 0, stream>>>(out.hnodes, out.top_nodes, (uint32_t*)(out.top_nodes + kTopNodesMax), kTopNodesMax, d_ntop);
-        HIPCK(hipGetLastError());
-        HIPCK(hipMemcpyAsync(&out.n_top, d_ntop, 4, hipMemcpyDeviceToHost, stream));
         HIPCK(hipStreamSynchronize(stream));
         out.hspace = sp;
         out.half_area_ratio = h_area[0] > 0.0f ? h_area[1] / h_area[0] : 1.0f;
@@ -747,6 +741,25 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
     out.n_nodes = n_nodes;
     out.max_depth = (uint32_t)root_hi.w;
     out.grid = make_qgrid_f(out.scene_lo, out.scene_hi);
+    return true;
+}
+
+// The breadth-first copy of the tree's top (k_top_nodes): built on first use by a kernel variant that stages it in LDS — an
+// experiment; not part of the default scene set-up.
+bool build_top_nodes(LbvhResult& r, hipStream_t stream, std::string& err)
+{
+    if (r.top_nodes || !r.hnodes || r.n_tris == 0) return true;
+    uint32_t* d_ntop = nullptr;
+    HIPCK(hipMalloc((void**)&d_ntop, 4));
+    hipError_t e = hipMalloc((void**)&r.top_nodes, (size_t)kTopNodesMax * (sizeof(HNode) + sizeof(uint32_t)));      // nodes, then their indices in hnodes
+    if (e == hipSuccess) {
+        k_top_nodes<<<1, 64, 0, stream>>>(r.hnodes, r.top_nodes, (uint32_t*)(r.top_nodes + kTopNodesMax), kTopNodesMax, d_ntop);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&r.n_top, d_ntop, 4, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d_ntop);
+    if (e != hipSuccess) { err = std::string("top nodes: ") + hipGetErrorString(e); return false; }
     return true;
 }
 

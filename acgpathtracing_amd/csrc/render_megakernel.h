@@ -26,7 +26,7 @@ constexpr uint32_t kCounterWords = kCulledCounter + kTailCounters;
 // 1.31 M triangles, 5 % slower at 20 k).  fp32 nodes otherwise, with triangle rounds at 8 lanes above kLargeSceneTris.
 constexpr int kVariantSync = 0, kVariantF32 = 1, kVariantF32Stats = 2, kVariantF32Large = 3, kVariantFastMath = 4;
 constexpr int kVariantF16 = 5, kVariantF16Stats = 6, kVariantF16W5 = 7, kVariantLights = 8, kVariantF16W5Deep = 9;
-constexpr int kVariantWf16 = 10, kVariantWf10 = 11;      // workgroup-level wavefront kernels (render_wavefront.hip)
+constexpr int kVariantWf = 10, kVariantWfStats = 11;      // the workgroup-level wavefront kernel (render_wavefront.hip) and its twin with time stamps
 constexpr int kDefaultVariant = kVariantF16W5;
 constexpr uint32_t kLargeSceneTris = 100000;
 constexpr uint32_t kWindowSceneTris = 50000;
@@ -80,6 +80,7 @@ int render_variant_count();
 const char* render_variant_name(int variant);
 const char* render_variant_kernel(int variant);   // the instantiation as a kernel trace prints it ("" for experiment variants)
 int render_variant_threads(int variant);
+int render_variant_top_nodes(int variant);      // > 0: the variant stages that many nodes of the tree's top in LDS (experiments)
 int render_variant_stack_cap(int variant);      // 0 = the whole stack in LDS
 int render_variant_node_format(int variant);   // 0 fp32 two-child; 7 / 8 / 9 fp16 two-child (min-max / rotated / rotated, flags in the multipliers); experiments: 1/2/4 16-bit grid, 3 four-wide 8-bit
 hipError_t render_occupancy(int variant, uint32_t stack_entries, uint32_t n_nodes, int* blocks_per_cu);

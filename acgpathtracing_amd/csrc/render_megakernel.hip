@@ -1159,12 +1159,12 @@ static const VariantDesc kVariants[] = {
     {PW(40, 16, 9, 256, 5, false, 0, 5, 2, false, 0, 0), 256, 9, "pw K40 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes with the rotate amounts in the multipliers' low bits, FIVE waves per SIMD (96 registers), five visits and two triangle tests per loop trip", 0, PWN(40, 16, 9, 256, 5, false, 0, 5, 2, false, 0, 0)},
     {PW(44, 16, 9, 256, 4, false, 0, 5, 2, true, 0, 0), 256, 9, "LIGHTS scene-driven area lights + MIS (light mode 1, opt-in: not the reference's estimator), fp16 sign-rotated nodes w4", 0, PWN(44, 16, 9, 256, 4, false, 0, 5, 2, true, 0, 0)},
     {PW(24, 16, 9, 256, 5, false, 0, 5, 2, false, -16, 0), 256, 9, "pw K24 L16 fp16 sign-rotated nodes, five waves per SIMD, for large scenes and deep trees: shade rounds at 24 parked lanes (rays are long there), a sliding window of 16 stack entries per lane in LDS, deeper ones moved to global memory four at a time", -16, PWN(24, 16, 9, 256, 5, false, 0, 5, 2, false, -16, 0)},
-    {nullptr, 0, 9, nullptr, 0, nullptr, 0},      // kVariantWf16: filled from render_wavefront.hip's table (variant_desc)
-    {nullptr, 0, 9, nullptr, 0, nullptr, 1},      // kVariantWf10
-    {nullptr, 0, 9, nullptr, 0, nullptr, 2},
+    {nullptr, 0, 9, nullptr, 0, nullptr, 0},      // kVariantWf: filled from render_wavefront.hip's table (variant_desc)
+    {nullptr, 0, 9, nullptr, 0, nullptr, 1},      // kVariantWfStats
+#ifdef ACGPT_EXPERIMENTS
+    {nullptr, 0, 9, nullptr, 0, nullptr, 2},      // wavefront 8 + 2 (two workgroups per CU), 8 + 8, 10 + 6
     {nullptr, 0, 9, nullptr, 0, nullptr, 3},
     {nullptr, 0, 9, nullptr, 0, nullptr, 4},
-#ifdef ACGPT_EXPERIMENTS
     // round 3: the shape of a trip through the BVH loop (visits per trip, triangle tests per round, lanes a round waits for)
     {PW(44, 1, 9, 256, 5, false, 0, 2, 1, false, 0), 256, 9, "r3 K44 L1 V2 T1 (visit, visit, test: a lane never waits more than one slot)"},
     {PW(44, 1, 9, 256, 5, false, 0, 3, 1, false, 0), 256, 9, "r3 K44 L1 V3 T1"},
@@ -1311,6 +1311,7 @@ const char* render_variant_name(int v) { return (v >= 0 && v < render_variant_co
 int render_variant_node_format(int v) { return (v >= 0 && v < render_variant_count()) ? kVariants[v].node_fmt : -1; }
 int render_variant_threads(int v) { return (v >= 0 && v < render_variant_count()) ? variant_desc(v).threads : 0; }
 int render_variant_stack_cap(int v) { return (v >= 0 && v < render_variant_count()) ? variant_desc(v).stack_cap : 0; }
+int render_variant_top_nodes(int v) { return (v >= 0 && v < render_variant_count()) ? kVariants[v].top_n : 0; }
 const char* render_variant_kernel(int v) { return (v >= 0 && v < render_variant_count()) ? variant_desc(v).kernel : ""; }
 
 static size_t variant_lds(const VariantDesc& d, uint32_t stack_entries, uint32_t n_nodes)

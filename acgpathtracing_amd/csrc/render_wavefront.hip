@@ -712,11 +712,13 @@ k_render_wf(const RenderArgsBox B)
 #define WF(...) k_render_wf<__VA_ARGS__>
 #define WFN(...) "k_render_wf<" #__VA_ARGS__ ">"
 static const WfDesc kWfVariants[] = {
-    {WF(12, 4, 512, 16, 16, 16, 5, 1, false), 12, 4, 512, 16, "wavefront: 12 trace + 4 shade waves per workgroup, 512 record slots in LDS, fp16 nodes, one workgroup per CU", WFN(12, 4, 512, 16, 16, 16, 5, 1, false)},
-    {WF(8, 2, 256, 16, 16, 16, 5, 2, false), 8, 2, 256, 16, "wavefront: 8 trace + 2 shade waves per workgroup, 256 record slots, fp16 nodes, two workgroups per CU (five waves per SIMD)", WFN(8, 2, 256, 16, 16, 16, 5, 2, false)},
+    {WF(12, 4, 512, 16, 16, 16, 5, 1, false), 12, 4, 512, 16, "wavefront: 12 trace + 4 shade waves per workgroup, 512 record slots in LDS, fp16 nodes, one workgroup per CU (a measured experiment: never chosen automatically)", WFN(12, 4, 512, 16, 16, 16, 5, 1, false)},
     {WF(12, 4, 512, 16, 16, 16, 5, 1, true), 12, 4, 512, 16, "wavefront 12 + 4 with per-role time stamps (pt_debug_wf)", WFN(12, 4, 512, 16, 16, 16, 5, 1, true)},
+#ifdef ACGPT_EXPERIMENTS
+    {WF(8, 2, 256, 16, 16, 16, 5, 2, false), 8, 2, 256, 16, "wavefront: 8 trace + 2 shade waves per workgroup, 256 record slots, fp16 nodes, two workgroups per CU (five waves per SIMD)", WFN(8, 2, 256, 16, 16, 16, 5, 2, false)},
     {WF(8, 8, 512, 16, 16, 16, 5, 1, true), 8, 8, 512, 16, "wavefront 8 + 8 with per-role time stamps", WFN(8, 8, 512, 16, 16, 16, 5, 1, true)},
     {WF(10, 6, 512, 16, 16, 16, 5, 1, true), 10, 6, 512, 16, "wavefront 10 + 6 with per-role time stamps", WFN(10, 6, 512, 16, 16, 16, 5, 1, true)},
+#endif
 };
 int wf_variant_count() { return (int)(sizeof(kWfVariants) / sizeof(kWfVariants[0])); }
 const WfDesc* wf_variant(int i) { return (i >= 0 && i < wf_variant_count()) ? &kWfVariants[i] : nullptr; }
