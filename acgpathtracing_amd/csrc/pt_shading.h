@@ -224,7 +224,9 @@ __device__ __forceinline__ bool shade_hit(const DeviceScene& sc, Late late, cons
     const float z1 = rnd(s);                                                     // :985-987
     const float z2 = rnd(s);
     pseed = s;
-    if (length(Ke) > 0.0f) { pd.radiance = Ke; pd.done = true; }                 // :992-1000
+    // :992-1000 tests length(Ke) > 0: sqrt(s) > 0 exactly when s > 0 (s = +0, a denormal, inf and NaN included), so the
+    // correctly rounded square root of the reference is not needed for the decision
+    if (dot(Ke, Ke) > 0.0f) { pd.radiance = Ke; pd.done = true; }
     else                   { pd.radiance = mk(0.0f); pd.done = false; }
     pd.weight = 0.0f;
     bool want_shadow = false;
@@ -268,7 +270,7 @@ __device__ __forceinline__ bool shade_hit_lights(const DeviceScene& sc, Late lat
     uint32_t s = pseed;
     pd.radiance = mk(0.0f); pd.weight = 0.0f;
     pd.nxt_org = org; pd.nxt_dir = dir;
-    if (length(Ke) > 0.0f) {
+    if (dot(Ke, Ke) > 0.0f) {                         // length(Ke) > 0, without the square root (see shade_hit)
         float w = 1.0f;
         if (depth > 0 && prev_pdf > 0.0f) {
             const float cos_l = fabsf(dot(N0, dir));
