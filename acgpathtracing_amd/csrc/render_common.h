@@ -188,6 +188,9 @@ __device__ __forceinline__ void refill_lanes(const RenderArgs& A, Late late, Que
                     if (outside) pxy = 0xFFFFFFFFu;
                 }
                 q.grp_pxy = pxy;
+                // a grant whose groups are all settled (pixels that cannot reach the scene box) or padding holds nothing to deal: drop
+                // it whole instead of handing out its items, 64 at a time, to lanes that find nothing in them
+                if (vote(pxy != 0xFFFFFFFFu) == 0ull) { q.res_count = 0u; continue; }
             }
         }
         const uint32_t want = (uint32_t)popc(idle);
