@@ -886,7 +886,8 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
         std::vector<float> key = {(float)p->width, (float)p->height, p->cameraEye.x, p->cameraEye.y, p->cameraEye.z, p->cameraU.x, p->cameraU.y, p->cameraU.z,
                                   p->cameraV.x, p->cameraV.y, p->cameraV.z, p->cameraW.x, p->cameraW.y, p->cameraW.z,
                                   c->bvh.scene_lo[0], c->bvh.scene_lo[1], c->bvh.scene_lo[2], c->bvh.scene_hi[0], c->bvh.scene_hi[1], c->bvh.scene_hi[2], 1.0f};
-        if (key != c->spans_key || memcmp(key.data(), c->spans_key.data(), key.size() * sizeof(float)) != 0) {
+        // (the last element records whether the spans could be computed at all: not part of the comparison)
+        if (key.size() != c->spans_key.size() || memcmp(key.data(), c->spans_key.data(), (key.size() - 1) * sizeof(float)) != 0) {
             std::vector<uint32_t> spans;
             const bool ok = row_spans(p, c->bvh.scene_lo, c->bvh.scene_hi, spans);
             key.back() = ok ? 1.0f : 0.0f;
