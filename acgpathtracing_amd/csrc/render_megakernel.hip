@@ -1203,6 +1203,13 @@ static const VariantDesc kVariants[] = {
     {PW(20, 12, 9, 256, 6, false, 0, 5, 2, false, -16), 256, 9, "r3 window-16 K20 L12 V5 T2, SIX waves per SIMD", -16},
     {PW(28, 12, 9, 256, 5, false, 0, 5, 2, false, -16), 256, 9, "r3 window-16 K28 L12 V5 T2", -16},
     {PW(16, 12, 9, 256, 5, false, 0, 5, 2, false, -16), 256, 9, "r3 window-16 K16 L12 V5 T2", -16},
+    {PW(24, 24, 9, 256, 5, false, 0, 5, 2, false, -16), 256, 9, "r3 window-16 K24 L24 V5 T2", -16},
+    {PW(24, 32, 9, 256, 5, false, 0, 5, 2, false, -16), 256, 9, "r3 window-16 K24 L32 V5 T2", -16},
+    {PW(24, 20, 9, 256, 5, false, 0, 5, 2, false, -16), 256, 9, "r3 window-16 K24 L20 V5 T2", -16},
+    {PW(24, 24, 9, 256, 5, false, 0, 5, 1, false, -16), 256, 9, "r3 window-16 K24 L24 V5 T1", -16},
+    {PW(24, 16, 9, 256, 5, false, 0, 5, 3, false, -16), 256, 9, "r3 window-16 K24 L16 V5 T3", -16},
+    {PW(24, 16, 9, 256, 5, false, 0, 4, 2, false, -16), 256, 9, "r3 window-16 K24 L16 V4 T2", -16},
+    {PW(24, 16, 9, 256, 5, false, 0, 3, 2, false, -16), 256, 9, "r3 window-16 K24 L16 V3 T2", -16},
     {PW(8, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K8 L16 V5 T2", 28},
     {PW(12, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K12 L16 V5 T2", 28},
     {PW(16, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K16 L16 V5 T2", 28},
