@@ -1162,145 +1162,7 @@ static const VariantDesc kVariants[] = {
     {nullptr, 0, 9, nullptr, 0, nullptr, 0},      // kVariantWf: filled from render_wavefront.hip's table (variant_desc)
     {nullptr, 0, 9, nullptr, 0, nullptr, 1},      // kVariantWfStats
 #ifdef ACGPT_EXPERIMENTS
-    {nullptr, 0, 9, nullptr, 0, nullptr, 2},      // wavefront 8 + 2 (two workgroups per CU), 8 + 8, 10 + 6
-    {nullptr, 0, 9, nullptr, 0, nullptr, 3},
-    {nullptr, 0, 9, nullptr, 0, nullptr, 4},
-    // round 3: the shape of a trip through the BVH loop (visits per trip, triangle tests per round, lanes a round waits for)
-    {PW(44, 1, 9, 256, 5, false, 0, 2, 1, false, 0), 256, 9, "r3 K44 L1 V2 T1 (visit, visit, test: a lane never waits more than one slot)"},
-    {PW(44, 1, 9, 256, 5, false, 0, 3, 1, false, 0), 256, 9, "r3 K44 L1 V3 T1"},
-    {PW(44, 8, 9, 256, 5, false, 0, 2, 1, false, 0), 256, 9, "r3 K44 L8 V2 T1"},
-    {PW(44, 8, 9, 256, 5, false, 0, 3, 1, false, 0), 256, 9, "r3 K44 L8 V3 T1"},
-    {PW(44, 1, 9, 256, 5, false, 0, 2, 2, false, 0), 256, 9, "r3 K44 L1 V2 T2"},
-    {PW(44, 8, 9, 256, 5, false, 0, 3, 2, false, 0), 256, 9, "r3 K44 L8 V3 T2"},
-    {PW(44, 1, 9, 256, 5, false, 0, 1, 1, false, 0), 256, 9, "r3 K44 L1 V1 T1"},
-    {PW(44, 8, 9, 256, 5, false, 0, 4, 2, false, 0), 256, 9, "r3 K44 L8 V4 T2"},
-    {PW(48, 1, 9, 256, 5, false, 0, 2, 1, false, 0), 256, 9, "r3 K48 L1 V2 T1"},
-    {PW(40, 1, 9, 256, 5, false, 0, 2, 1, false, 0), 256, 9, "r3 K40 L1 V2 T1"},
-    {PW(44, 4, 9, 256, 5, false, 0, 2, 1, false, 0), 256, 9, "r3 K44 L4 V2 T1"},
-    {PW(44, 24, 9, 256, 5, false, 0, 5, 2, false, 0), 256, 9, "r3 K44 L24 V5 T2"},
-    {PW(44, 32, 9, 256, 5, false, 0, 5, 2, false, 0), 256, 9, "r3 K44 L32 V5 T2"},
-    {PW(44, 16, 9, 256, 4, false, 0, 5, 2, false, 0), 256, 9, "r3 the default loop at FOUR waves per SIMD (128 registers), whole stack in LDS"},
-    {PW(44, 16, 9, 256, 4, false, 0, 5, 2, false, 28), 256, 9, "r3 four waves per SIMD, 28 stack entries in LDS", 28},
-    // the deep-tree kernel (1.31 M triangles: 27.7 visits per ray): when to leave the BVH loop for a shade round, how long a trip is
-    {PW(36, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K36 L16 V5 T2", 28},
-    {PW(28, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K28 L16 V5 T2", 28},
-    {PW(20, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K20 L16 V5 T2", 28},
-    {PW(44, 8, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K44 L8 V5 T2", 28},
-    {PW(44, 16, 9, 256, 5, false, 0, 8, 2, false, 28), 256, 9, "r3 deep K44 L16 V8 T2", 28},
-    {PW(32, 8, 9, 256, 5, false, 0, 8, 2, false, 28), 256, 9, "r3 deep K32 L8 V8 T2", 28},
-    {PW(52, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K52 L16 V5 T2", 28},
-    {PW(20, 12, 9, 256, 5, false, 0, 5, 2, false, -16), 256, 9, "r3 window-16 K20 L12 V5 T2", -16},
-    {PW(44, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r2's deep-tree kernel: K44 L16, 28 stack entries in LDS, the rest in global memory, tested per access", 28},
-    // the top of the tree from LDS instead of through the texture-address path
-    {PW(40, 16, 9, 256, 5, false, 0, 5, 2, false, 0, 15), 256, 9, "r3 default + top 15 nodes in LDS", 0, "", -1, 15},
-    {PW(40, 16, 9, 256, 5, false, 0, 5, 2, false, 0, 63), 256, 9, "r3 default + top 63 nodes in LDS", 0, "", -1, 63},
-    {PW(40, 16, 9, 256, 5, false, 0, 5, 2, false, -16, 255), 256, 9, "r3 K40 window-16 + top 255 nodes in LDS", -16, "", -1, 255},
-    {PW(24, 16, 9, 256, 5, false, 0, 5, 2, false, -16, 63), 256, 9, "r3 large-scene kernel + top 63 nodes in LDS", -16, "", -1, 63},
-    {PW(24, 16, 9, 256, 5, false, 0, 5, 2, false, -16, 255), 256, 9, "r3 large-scene kernel + top 255 nodes in LDS", -16, "", -1, 255},
-    {PW(36, 16, 9, 256, 5, false, 0, 5, 2, false, -16), 256, 9, "r3 window-16 K36 L16 V5 T2", -16},
-    {PW(44, 16, 9, 256, 5, false, 0, 5, 2, false, -16), 256, 9, "r3 window-16 K44 L16 V5 T2", -16},
-    {PW(20, 12, 9, 256, 5, false, 0, 5, 2, false, -32), 256, 9, "r3 window-32 K20 L12 V5 T2", -32},
-    {PW(20, 12, 9, 256, 6, false, 0, 5, 2, false, -16), 256, 9, "r3 window-16 K20 L12 V5 T2, SIX waves per SIMD", -16},
-    {PW(28, 12, 9, 256, 5, false, 0, 5, 2, false, -16), 256, 9, "r3 window-16 K28 L12 V5 T2", -16},
-    {PW(16, 12, 9, 256, 5, false, 0, 5, 2, false, -16), 256, 9, "r3 window-16 K16 L12 V5 T2", -16},
-    {PW(24, 24, 9, 256, 5, false, 0, 5, 2, false, -16), 256, 9, "r3 window-16 K24 L24 V5 T2", -16},
-    {PW(24, 32, 9, 256, 5, false, 0, 5, 2, false, -16), 256, 9, "r3 window-16 K24 L32 V5 T2", -16},
-    {PW(24, 20, 9, 256, 5, false, 0, 5, 2, false, -16), 256, 9, "r3 window-16 K24 L20 V5 T2", -16},
-    {PW(24, 24, 9, 256, 5, false, 0, 5, 1, false, -16), 256, 9, "r3 window-16 K24 L24 V5 T1", -16},
-    {PW(24, 16, 9, 256, 5, false, 0, 5, 3, false, -16), 256, 9, "r3 window-16 K24 L16 V5 T3", -16},
-    {PW(24, 16, 9, 256, 5, false, 0, 4, 2, false, -16), 256, 9, "r3 window-16 K24 L16 V4 T2", -16},
-    {PW(24, 16, 9, 256, 5, false, 0, 3, 2, false, -16), 256, 9, "r3 window-16 K24 L16 V3 T2", -16},
-    {PW(8, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K8 L16 V5 T2", 28},
-    {PW(12, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K12 L16 V5 T2", 28},
-    {PW(16, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K16 L16 V5 T2", 28},
-    {PW(24, 16, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K24 L16 V5 T2", 28},
-    {PW(16, 8, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K16 L8 V5 T2", 28},
-    {PW(20, 8, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K20 L8 V5 T2", 28},
-    {PW(24, 8, 9, 256, 5, false, 0, 5, 2, false, 28), 256, 9, "r3 deep K24 L8 V5 T2", 28},
-    {PW(20, 12, 9, 256, 5, false, 0, 4, 2, false, 28), 256, 9, "r3 deep K20 L12 V4 T2", 28},
-    {PW(20, 12, 9, 256, 5, false, 0, 6, 2, false, 28), 256, 9, "r3 deep K20 L12 V6 T2", 28},
-    // the same question for the L2-resident scenes (whole stack in LDS)
-    {PW(36, 16, 9, 256, 5, false, 0, 5, 2, false, 0), 256, 9, "r3 K36 L16 V5 T2"},
-    {PW(28, 16, 9, 256, 5, false, 0, 5, 2, false, 0), 256, 9, "r3 K28 L16 V5 T2"},
-    {PW(44, 16, 9, 256, 5, false, 0, 5, 2, false, 0), 256, 9, "r2's default kernel: K44 L16 V5 T2"},
-    {PW(48, 16, 9, 256, 5, false, 0, 5, 2, false, 0), 256, 9, "r3 K48 L16 V5 T2"},
-#if ACGPT_EXPERIMENTS >= 2
-    {k_render_pw<40, 8, 0, 256, 4, false, 0, 1>, 256, 0, "pw K40 L8 fp32 w4, register stack top"},
-    {k_render_pw<48, 8, 0, 256, 4, false>, 256, 0, "pw K48 L8 fp32 w4, LDS-only stack"},
-    {k_render_pw<48, 8, 0, 256, 5, false, 0, 1>, 256, 0, "pw K48 L8 fp32 w5 (register-capped, spills)"},
-    {k_render_pw<44, 16, 7, 256, 4, false, 0, 2, 2>, 256, 7, "pw K44 L16 fp16 nodes, per-axis min / max, V2 T2"},
-    {k_render_pw<48, 8, 7, 256, 4, false, 0, 2>, 256, 7, "pw K48 L8 fp16 nodes, per-axis min / max, V2"},
-    {k_render_pw<48, 8, 1, 256, 4, false, 0, 1>, 256, 1, "pw K48 L8 q16 nodes w4"},
-    {k_render_pw<48, 8, 2, 1024, 4, false, 0, 1>, 1024, 2, "pw K48 L8 q16 nodes in LDS, 1024 threads"},
-    {k_render_pw<48, 8, 0, 256, 4, false, 1, 1>, 256, 0, "DIAG +12 VALU per inner step"},
-    {k_render_pw<48, 8, 0, 256, 4, false, 2, 1>, 256, 0, "DIAG +2 loads per inner step"},
-    {k_render_pw<48, 8, 3, 256, 4, false, 0, 1>, 256, 3, "pw K48 L8 four-wide 8-bit nodes w4"},
-    {k_render_pw<48, 8, 3, 256, 4, true, 0, 1>, 256, 3, "four-wide + scheduler stats"},
-    {k_render_pw<44, 16, 3, 256, 4, false, 0, 2, 2>, 256, 3, "pw K44 L16 T2 four-wide 8-bit nodes"},
-    {k_render_pw<48, 12, 0, 256, 4, false, 0, 1>, 256, 0, "pw K48 L12 fp32 w4, one visit per loop trip"},
-    {k_render_pw<48, 12, 0, 256, 4, false, 0, 3>, 256, 0, "pw K48 L12 fp32 w4, three visits per loop trip"},
-    {k_render_pw<44, 12, 0, 256, 4, false, 0, 2, 2>, 256, 0, "pw K44 L12 fp32 w4, two visits and two triangle tests per loop trip"},
-    {k_render_pw<44, 16, 0, 256, 4, false, 0, 2, 3>, 256, 0, "pw K44 L16 V2 T3"},
-    {k_render_pw<44, 16, 6, 256, 4, false, 0, 2, 2>, 256, 0, "pw K44 L16 V2 T2 centre / half-extent nodes"},
-    {k_render_pw<44, 16, 4, 256, 4, false, 0, 2, 2>, 256, 4, "pw K44 L16 V2 T2 q16 nodes, fma decode"},
-    {k_render_pw<48, 12, 5, 256, 4, false, 0, 1>, 256, 0, "pw K48 L12 fp32 w4, two-step slab test (p - o) * (1/d)"},
-    {k_render_pw<44, 16, 8, 256, 4, false, 0, 2, 2>, 256, 8, "pw K44 L16 fp16 nodes, sign-rotated planes (no per-axis min / max) V2 T2"},
-    {k_render_pw<48, 8, 8, 256, 4, false, 0, 2>, 256, 8, "pw K48 L8 fp16 nodes, sign-rotated planes V2"},
-    {k_render_pw<48, 16, 8, 256, 4, false, 0, 2, 2>, 256, 8, "pw K48 L16 fp16 sign-rotated V2 T2"},
-    {k_render_pw<40, 16, 8, 256, 4, false, 0, 2, 2>, 256, 8, "pw K40 L16 fp16 sign-rotated V2 T2"},
-    {k_render_pw<44, 16, 8, 256, 5, false, 0, 3, 2>, 256, 8, "pw K44 L16 fp16 sign-rotated V3 T2 w5"},
-    {k_render_pw<44, 16, 8, 256, 5, false, 0, 2, 2>, 256, 8, "pw K44 L16 fp16 sign-rotated V2 T2 w5"},
-    {k_render_pw<44, 16, 8, 256, 4, false, 0, 4, 2>, 256, 8, "pw K44 L16 fp16 sign-rotated V4 T2"},
-    {k_render_pw<44, 16, 8, 256, 4, false, 0, 3, 3>, 256, 8, "pw K44 L16 fp16 sign-rotated V3 T3"},
-    {k_render_pw<44, 12, 8, 256, 4, false, 0, 3, 2>, 256, 8, "pw K44 L12 fp16 sign-rotated V3 T2"},
-    {k_render_pw<44, 20, 8, 256, 4, false, 0, 3, 2>, 256, 8, "pw K44 L20 fp16 sign-rotated V3 T2"},
-    {k_render_pw<40, 16, 8, 256, 4, false, 0, 3, 2>, 256, 8, "pw K40 L16 fp16 sign-rotated V3 T2"},
-    {k_render_pw<48, 16, 8, 256, 4, false, 0, 3, 2>, 256, 8, "pw K48 L16 fp16 sign-rotated V3 T2"},
-    {k_render_pw<48, 8, 8, 256, 4, false, 0, 3>, 256, 8, "pw K48 L8 fp16 sign-rotated V3 T1"},
-    {k_render_pw<40, 16, 7, 256, 4, false, 0, 2, 2>, 256, 7, "pw K40 L16 fp16 V2 T2"},
-    {k_render_pw<48, 16, 7, 256, 4, false, 0, 2, 2>, 256, 7, "pw K48 L16 fp16 V2 T2"},
-    {k_render_pw<44, 12, 7, 256, 4, false, 0, 2, 2>, 256, 7, "pw K44 L12 fp16 V2 T2"},
-    {k_render_pw<44, 24, 7, 256, 4, false, 0, 2, 2>, 256, 7, "pw K44 L24 fp16 V2 T2"},
-    {k_render_pw<44, 16, 7, 256, 4, false, 0, 3, 2>, 256, 7, "pw K44 L16 fp16 V3 T2"},
-    {k_render_pw<44, 16, 7, 256, 5, false, 0, 2, 2>, 256, 7, "pw K44 L16 fp16 V2 T2 w5"},
-    {k_render_pw<40, 16, 7, 256, 5, false, 0, 2, 2>, 256, 7, "pw K40 L16 fp16 V2 T2 w5"},
-    {k_render_pw<48, 16, 7, 256, 5, false, 0, 2, 2>, 256, 7, "pw K48 L16 fp16 V2 T2 w5"},
-    {k_render_pw<44, 12, 7, 256, 5, false, 0, 2, 2>, 256, 7, "pw K44 L12 fp16 V2 T2 w5"},
-    {k_render_pw<44, 20, 7, 256, 5, false, 0, 2, 2>, 256, 7, "pw K44 L20 fp16 V2 T2 w5"},
-    {k_render_pw<44, 16, 7, 256, 5, false, 0, 2, 1>, 256, 7, "pw K44 L16 fp16 V2 T1 w5"},
-    {k_render_pw<44, 16, 7, 256, 5, false, 0, 2, 3>, 256, 7, "pw K44 L16 fp16 V2 T3 w5"},
-    {k_render_pw<44, 16, 7, 256, 6, false, 0, 2, 2>, 256, 7, "pw K44 L16 fp16 V2 T2 w6"},
-    {k_render_pw<44, 16, 0, 256, 5, false, 0, 2, 2>, 256, 0, "pw K44 L16 fp32 V2 T2 w5"},
-    {k_render_pw<44, 16, 6, 256, 5, false, 0, 2, 2>, 256, 0, "pw K44 L16 fp32 centre / half-extent V2 T2 w5"},
-    {k_render_pw<48, 16, 8, 256, 5, false, 0, 2, 2>, 256, 8, "pw K48 L16 fp16 sign-rotated V2 T2 w5"},
-    {k_render_pw<40, 16, 8, 256, 5, false, 0, 2, 2>, 256, 8, "pw K40 L16 fp16 sign-rotated V2 T2 w5"},
-    {k_render_pw<44, 16, 9, 256, 5, false, 0, 3, 2>, 256, 9, "pw K44 L16 fp16 sign-rotated, rotate amounts in the multipliers' low bits, V3 T2 w5"},
-    {k_render_pw<44, 16, 9, 256, 4, false, 0, 3, 2>, 256, 9, "pw K44 L16 fp16 sign-rotated, rotate amounts in the multipliers' low bits, V3 T2 w4"},
-    {k_render_pw<44, 16, 9, 256, 5, false, 0, 3, 2, false, 28>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) w5, 28 stack entries in LDS", 28},
-    {k_render_pw<44, 16, 9, 256, 5, false, 0, 2, 2>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) V2 T2 w5"},
-    {k_render_pw<44, 16, 9, 256, 5, false, 0, 4, 2>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) V4 T2 w5"},
-    {k_render_pw<40, 16, 9, 256, 5, false, 0, 3, 2>, 256, 9, "pw K40 L16 fp16 sign-rotated (low bits) V3 T2 w5"},
-    {k_render_pw<48, 16, 9, 256, 5, false, 0, 3, 2>, 256, 9, "pw K48 L16 fp16 sign-rotated (low bits) V3 T2 w5"},
-    {k_render_pw<44, 12, 9, 256, 5, false, 0, 3, 2>, 256, 9, "pw K44 L12 fp16 sign-rotated (low bits) V3 T2 w5"},
-    {k_render_pw<44, 20, 9, 256, 5, false, 0, 3, 2>, 256, 9, "pw K44 L20 fp16 sign-rotated (low bits) V3 T2 w5"},
-    {k_render_pw<44, 16, 9, 256, 5, false, 0, 3, 3>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) V3 T3 w5"},
-    {k_render_pw<44, 16, 9, 256, 5, false, 0, 3, 1>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) V3 T1 w5"},
-    {k_render_pw<44, 16, 9, 256, 6, false, 0, 3, 2>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) V3 T2 w6"},
-    {k_render_pw<44, 16, 9, 256, 5, false, 0, 4, 2, false, 28>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) V4 T2 w5, 28 stack entries in LDS", 28},
-    {k_render_pw<44, 16, 7, 256, 5, false, 0, 3, 2>, 256, 7, "pw K44 L16 fp16 min / max V3 T2 w5 (the default before the rotate amounts moved into the multipliers)"},
-    {k_render_pw<44, 16, 9, 256, 5, false, 0, 6, 2>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) V6 T2 w5"},
-    {k_render_pw<44, 12, 9, 256, 5, false, 0, 5, 2>, 256, 9, "pw K44 L12 fp16 sign-rotated (low bits) V5 T2 w5"},
-    {k_render_pw<44, 20, 9, 256, 5, false, 0, 5, 2>, 256, 9, "pw K44 L20 fp16 sign-rotated (low bits) V5 T2 w5"},
-    {k_render_pw<40, 16, 9, 256, 5, false, 0, 5, 2>, 256, 9, "pw K40 L16 fp16 sign-rotated (low bits) V5 T2 w5"},
-    {k_render_pw<48, 16, 9, 256, 5, false, 0, 5, 2>, 256, 9, "pw K48 L16 fp16 sign-rotated (low bits) V5 T2 w5"},
-    {k_render_pw<44, 16, 9, 256, 5, false, 0, 5, 1>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) V5 T1 w5"},
-    {k_render_pw<36, 16, 9, 256, 5, false, 0, 5, 2>, 256, 9, "pw K36 L16 fp16 sign-rotated (low bits) V5 T2 w5"},
-    {k_render_pw<44, 24, 9, 256, 5, false, 0, 5, 2>, 256, 9, "pw K44 L24 fp16 sign-rotated (low bits) V5 T2 w5"},
-    {k_render_pw<44, 16, 9, 256, 5, false, 0, 8, 2>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) V8 T2 w5"},
-    {k_render_pw<44, 16, 9, 256, 5, false, 0, 5, 3>, 256, 9, "pw K44 L16 fp16 sign-rotated (low bits) V5 T3 w5"},
-    {k_render_pw<44, 16, 7, 256, 5, false, 0, 3, 2, false, 28>, 256, 7, "pw K44 L16 fp16 min / max V3 T2 w5, 28 stack entries in LDS", 28},
-    {k_render_pw<44, 16, 7, 256, 5, false, 0, 5, 2>, 256, 7, "pw K44 L16 fp16 min / max V5 T2 w5"},
-#endif
+#include "render_experiments.inc"
 #endif
 };
 int render_variant_count() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
