@@ -74,7 +74,7 @@ ABI_SYMBOLS = [
     "pt_host_malloc_mapped", "pt_host_free_mapped", "pt_abi_version",
 ]
 # ... and include/acgpt_test.h (test hooks and diagnostics; same library)
-TEST_SYMBOLS = ["pt_bench_traversal", "pt_selftest", "pt_debug_wave_times", "pt_debug_queue_progress", "pt_debug_wf", "pt_debug_queue_order", "pt_debug_pixel_classes", "pt_read_morton"]
+TEST_SYMBOLS = ["pt_bench_traversal", "pt_selftest", "pt_debug_wave_times", "pt_debug_queue_progress", "pt_debug_wf", "pt_debug_queue_order", "pt_debug_pixel_classes", "pt_debug_row_spans", "pt_read_morton"]
 
 _hip = None
 _host = None
@@ -136,6 +136,7 @@ def hip():
     L.pt_debug_wf.argtypes = [vp, vp]; L.pt_debug_wf.restype = C.c_int
     L.pt_debug_queue_order.argtypes = [vp, C.c_int]; L.pt_debug_queue_order.restype = C.c_int
     L.pt_debug_pixel_classes.argtypes = [vp, C.c_int]; L.pt_debug_pixel_classes.restype = C.c_int
+    L.pt_debug_row_spans.argtypes = [C.POINTER(PathTraceParams), vp, vp, vp]; L.pt_debug_row_spans.restype = C.c_int
     L.pt_device_malloc.argtypes = [vp, C.POINTER(vp), sz]; L.pt_device_malloc.restype = C.c_int
     L.pt_device_free.argtypes = [vp, vp]; L.pt_device_free.restype = C.c_int
     L.pt_device_memset.argtypes = [vp, vp, C.c_int, sz]; L.pt_device_memset.restype = C.c_int

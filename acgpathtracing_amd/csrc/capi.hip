@@ -1137,6 +1137,17 @@ PT_API int pt_debug_queue_order(pt_ctx* c, int mode)
     return 0;
 }
 
+// The host side of the pixel classes alone (no context, no GPU): out = 2 * params->height words, {outer lo | hi << 16, inner lo | hi << 16}
+// per image row.  Returns 0 when the spans could be computed, 1 when they could not (box not entirely in front of the eye, ...).
+PT_API int pt_debug_row_spans(const pt_params* p, const float* box_lo, const float* box_hi, uint32_t* out)
+{
+    if (!p || !box_lo || !box_hi || !out || p->width == 0 || p->height == 0 || p->width > 65535u || p->height > 32767u) return 2;
+    std::vector<uint32_t> spans;
+    const bool ok = row_spans(p, box_lo, box_hi, spans);
+    memcpy(out, spans.data(), spans.size() * sizeof(uint32_t));
+    return ok ? 0 : 1;
+}
+
 PT_API int pt_debug_pixel_classes(pt_ctx* c, int on)
 {
     if (!c) return fail(c, "pt_debug_pixel_classes: null context");

@@ -63,6 +63,10 @@ int pt_debug_queue_order(pt_ctx* ctx, int mode);
  * which every ray does (their path starts skip the cull test).  Same image bits and the same ray / path counters either way;
  * pt_stats.culled_rays differs (it counts what was settled without a traversal). */
 int pt_debug_pixel_classes(pt_ctx* ctx, int on);
+/* The host computation behind them, callable without a context or a GPU: for the camera and image size of `params` and the box
+ * [box_lo, box_hi], out[2 * y] = outer columns lo | hi << 16 and out[2 * y + 1] = inner columns lo | hi << 16 of image row y
+ * (2 * height words).  0 = computed, 1 = no classes for this view (box not entirely in front of the eye, degenerate frame). */
+int pt_debug_row_spans(const pt_params* params, const float* box_lo, const float* box_hi, uint32_t* out);
 /* Diagnostic: 18 values of the last launch.  [17]: a windowed-stack kernel's moves of stack entries between the LDS window and
  * global memory (wave-level events).  [0..16]: after a launch of a wavefront kernel variant (render_wavefront.hip), summed over the waves of the grid,
  * times in 10 ns ticks: trace waves {total, idle}, shade waves {total, idle, deal time / rounds / records, hit-shading time /
