@@ -47,7 +47,8 @@ class Stats(C.Structure):
     _fields_ = [("radiance_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("paths", C.c_uint64),
                 ("kernel_ms", C.c_float), ("launch_ms", C.c_float), ("pixels", C.c_uint32), ("grid_blocks", C.c_uint32), ("sample_chunks", C.c_uint32), ("variant", C.c_uint32),
                 ("trav_wave_steps", C.c_uint64), ("trav_lane_steps", C.c_uint64),
-                ("shade_wave_rounds", C.c_uint64), ("shade_lane_rounds", C.c_uint64), ("culled_rays", C.c_uint64)]
+                ("shade_wave_rounds", C.c_uint64), ("shade_lane_rounds", C.c_uint64), ("culled_rays", C.c_uint64),
+                ("math_mode", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class BvhInfo(C.Structure):
@@ -61,13 +62,14 @@ class BvhInfo(C.Structure):
 assert C.sizeof(PathTraceParams) == 168
 assert C.sizeof(Material) == 40
 assert C.sizeof(AreaLight) == 60
-assert C.sizeof(Stats) == 88 and C.sizeof(BvhInfo) == 80          # ABI version 2 (include/acgpt.h)
-ABI_VERSION = 2
+assert C.sizeof(Stats) == 96 and C.sizeof(BvhInfo) == 80          # ABI version 3 (include/acgpt.h)
+ABI_VERSION = 3
+MATH_IEEE, MATH_FAST = 0, 1                                        # pt_set_math_mode
 
 # every symbol include/acgpt.h declares (the drop-in boundary) ...
 ABI_SYMBOLS = [
     "pt_create", "pt_create_multi", "pt_device_count", "pt_destroy", "pt_last_error", "pt_set_scene", "pt_set_build_mode", "pt_scene_handle", "pt_get_bvh_info",
-    "pt_launch", "pt_launch_frames", "pt_resolve_framebuffer", "pt_set_partition", "pt_set_sample_chunks", "pt_set_light_mode", "pt_set_scratch_limit", "pt_set_tuning",
+    "pt_launch", "pt_launch_frames", "pt_resolve_framebuffer", "pt_set_partition", "pt_set_sample_chunks", "pt_set_light_mode", "pt_set_math_mode", "pt_set_scratch_limit", "pt_set_tuning",
     "pt_variant_name", "pt_variant_kernel", "pt_kernel_source_hash", "pt_set_stream", "pt_get_stats",
     "pt_trace_closest", "pt_trace_any",
     "pt_device_malloc", "pt_device_free", "pt_device_memset", "pt_copy_to_host", "pt_copy_to_device",
@@ -107,7 +109,7 @@ def hip():
     L.pt_create.argtypes = [C.POINTER(vp), C.c_int]; L.pt_create.restype = C.c_int
     L.pt_create_multi.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]; L.pt_create_multi.restype = C.c_int
     L.pt_device_count.argtypes = [vp]; L.pt_device_count.restype = C.c_int
-    L.pt_variant_kernel.argtypes = [C.c_int]; L.pt_variant_kernel.restype = C.c_char_p
+    L.pt_variant_kernel.argtypes = [C.c_int, C.c_int]; L.pt_variant_kernel.restype = C.c_char_p
     L.pt_kernel_source_hash.argtypes = []; L.pt_kernel_source_hash.restype = C.c_char_p
     L.pt_destroy.argtypes = [vp]; L.pt_destroy.restype = None
     L.pt_last_error.argtypes = [vp]; L.pt_last_error.restype = C.c_char_p
@@ -121,6 +123,7 @@ def hip():
     L.pt_set_partition.argtypes = [vp, C.c_int, C.c_int]; L.pt_set_partition.restype = C.c_int
     L.pt_set_sample_chunks.argtypes = [vp, C.c_int]; L.pt_set_sample_chunks.restype = C.c_int
     L.pt_set_light_mode.argtypes = [vp, C.c_int]; L.pt_set_light_mode.restype = C.c_int
+    L.pt_set_math_mode.argtypes = [vp, C.c_int]; L.pt_set_math_mode.restype = C.c_int
     L.pt_set_scratch_limit.argtypes = [vp, C.c_size_t]; L.pt_set_scratch_limit.restype = C.c_int
     L.pt_set_tuning.argtypes = [vp, C.c_int, C.c_int]; L.pt_set_tuning.restype = C.c_int
     L.pt_variant_name.argtypes = [C.c_int]; L.pt_variant_name.restype = C.c_char_p

@@ -27,7 +27,7 @@
 static_assert(sizeof(pt_params) == 168, "pt_params must mirror PathTraceParams (168 bytes)");
 static_assert(sizeof(pt_material) == 40, "pt_material must mirror Material (40 bytes)");
 static_assert(sizeof(pt_area_light) == 60, "pt_area_light must mirror AreaLight (60 bytes)");
-static_assert(sizeof(pt_stats) == 88 && sizeof(pt_bvh_info) == 80, "ABI version 2: a change of these layouts bumps pt_abi_version");
+static_assert(sizeof(pt_stats) == 96 && sizeof(pt_bvh_info) == 80, "ABI version 3: a change of these layouts bumps pt_abi_version");
 
 struct pt_multi;
 
@@ -44,6 +44,7 @@ struct pt_ctx {
     uint32_t n_lights = 0;
     float light_area = 0.0f;
     int light_mode = 0;                       // 0 the reference's estimator, 1 scene lights + MIS (pt_set_light_mode)
+    int math_mode = PT_MATH_FAST;             // arithmetic of the shading code (pt_set_math_mode): the reference's own build uses nvcc --use_fast_math
     uint32_t stack_entries = 8;
     int blocks_per_cu = 0;        // from the occupancy query for the current stack size
     int tune_blocks_per_cu = 0;   // user override
@@ -135,7 +136,7 @@ struct pt_multi {
     pt_stats group_stats;
 };
 
-PT_API uint32_t pt_abi_version(void) { return 2u; }
+PT_API uint32_t pt_abi_version(void) { return 3u; }
 
 PT_API const char* pt_last_error(pt_ctx* ctx)
 {
@@ -302,7 +303,7 @@ static int pick_variant(const pt_ctx* c)
     if (!half_ok) return large ? ptd::kVariantF32Large : ptd::kVariantF32;
     if (c->bvh.n_tris > ptd::kWindowSceneTris) return ptd::kVariantF16W5Deep;     // long rays: earlier shade rounds, windowed stack
     int w5_blocks = 0;      // do five workgroups of the five-wave kernel fit a CU with this tree's stack depth?
-    if (ptd::render_occupancy(ptd::kVariantF16W5, c->stack_entries, c->bvh.n_nodes, &w5_blocks) == hipSuccess && w5_blocks >= 5) return ptd::kVariantF16W5;
+    if (ptd::render_occupancy(ptd::kVariantF16W5, c->math_mode, c->stack_entries, c->bvh.n_nodes, &w5_blocks) == hipSuccess && w5_blocks >= 5) return ptd::kVariantF16W5;
     return ptd::kVariantF16W5Deep;      // small scene, deep tree: the windowed stack keeps five workgroups on a CU
 }
 
@@ -316,7 +317,7 @@ static int size_stack(pt_ctx* c)
     need = (need + 3u) & ~3u;
     if (need > 128u) return fail(c, "pt_set_scene: BVH deeper than the traversal stack supports");
     c->stack_entries = need;
-    CK(c, ptd::render_occupancy(c->variant, c->stack_entries, c->bvh.n_nodes, &c->blocks_per_cu));
+    CK(c, ptd::render_occupancy(c->variant, c->math_mode, c->stack_entries, c->bvh.n_nodes, &c->blocks_per_cu));
     if (c->blocks_per_cu < 1) return fail(c, "render kernel does not fit on a CU with this stack size");
     return 0;
 }
@@ -449,6 +450,17 @@ static int set_light_mode_one(pt_ctx* c, int mode)
     return 0;
 }
 
+static int set_math_mode_one(pt_ctx* c, int mode)
+{
+    if (!c) return fail(nullptr, "pt_set_math_mode: null context");
+    if (mode != PT_MATH_IEEE && mode != PT_MATH_FAST) return fail(c, "pt_set_math_mode: PT_MATH_IEEE (0) or PT_MATH_FAST (1)");
+    c->math_mode = mode;
+    CK(c, hipSetDevice(c->device));           // the twin's occupancy (its register count differs)
+    CK(c, ptd::render_occupancy(c->variant, c->math_mode, c->stack_entries, c->bvh.n_nodes, &c->blocks_per_cu));
+    if (c->blocks_per_cu < 1) return fail(c, "pt_set_math_mode: the kernel of this mode does not fit the current scene in LDS");
+    return 0;
+}
+
 static int set_sample_chunks_one(pt_ctx* c, int chunks)
 {
     if (!c) return fail(nullptr, "pt_set_sample_chunks: null context");
@@ -468,7 +480,7 @@ static int set_tuning_one(pt_ctx* c, int blocks_per_cu, int variant)
     c->variant = variant < 0 ? pick_variant(c) : variant;
     if (ptd::render_variant_node_format(c->variant) == 3) { if (int rc = ensure_wide(c)) return rc; }
     if (int rc = ensure_top(c)) return rc;
-    CK(c, ptd::render_occupancy(c->variant, c->stack_entries, c->bvh.n_nodes, &c->blocks_per_cu));
+    CK(c, ptd::render_occupancy(c->variant, c->math_mode, c->stack_entries, c->bvh.n_nodes, &c->blocks_per_cu));
     if (c->blocks_per_cu < 1) return fail(c, "pt_set_tuning: this kernel variant does not fit the current scene in LDS");
     return 0;
 }
@@ -500,6 +512,12 @@ PT_API int pt_set_light_mode(pt_ctx* c, int mode)
     return set_light_mode_one(c, mode);
 }
 
+PT_API int pt_set_math_mode(pt_ctx* c, int mode)
+{
+    if (c && c->multi) return on_every_rank(c, [&](pt_ctx* r, int) { return set_math_mode_one(r, mode); });
+    return set_math_mode_one(c, mode);
+}
+
 PT_API int pt_set_sample_chunks(pt_ctx* c, int chunks)
 {
     if (c && c->multi) return on_every_rank(c, [&](pt_ctx* r, int) { return set_sample_chunks_one(r, chunks); });
@@ -523,9 +541,9 @@ PT_API const char* pt_variant_name(int variant)
     return (variant >= 0 && variant < ptd::render_variant_count()) ? ptd::render_variant_name(variant) : nullptr;
 }
 
-PT_API const char* pt_variant_kernel(int variant)
+PT_API const char* pt_variant_kernel(int variant, int math_mode)
 {
-    return (variant >= 0 && variant < ptd::render_variant_count()) ? ptd::render_variant_kernel(variant) : nullptr;
+    return (variant >= 0 && variant < ptd::render_variant_count()) ? ptd::render_variant_kernel(variant, math_mode) : nullptr;
 }
 
 #ifndef ACGPT_KERNEL_SRC_HASH
@@ -782,7 +800,7 @@ static int launch_frames_single(pt_ctx* c, const pt_params* p, uint32_t n_frames
         total.kernel_ms += s.kernel_ms; total.launch_ms += s.launch_ms;
         total.trav_wave_steps += s.trav_wave_steps; total.trav_lane_steps += s.trav_lane_steps;
         total.shade_wave_rounds += s.shade_wave_rounds; total.shade_lane_rounds += s.shade_lane_rounds;
-        total.pixels = s.pixels; total.grid_blocks = s.grid_blocks; total.sample_chunks = s.sample_chunks; total.variant = s.variant;
+        total.pixels = s.pixels; total.grid_blocks = s.grid_blocks; total.sample_chunks = s.sample_chunks; total.variant = s.variant; total.math_mode = s.math_mode;
         done += n;
     }
     c->stats = total;
@@ -914,7 +932,7 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
     const int variant = c->light_mode == 1 ? ptd::kVariantLights : c->variant;
     int fit = c->blocks_per_cu;
     if (variant != c->variant || fit < 1) {   // (fit < 1: no scene yet — empty world, every ray misses)
-        CK(c, ptd::render_occupancy(variant, c->stack_entries, c->bvh.n_nodes, &fit));
+        CK(c, ptd::render_occupancy(variant, c->math_mode, c->stack_entries, c->bvh.n_nodes, &fit));
         if (variant == c->variant) c->blocks_per_cu = fit;
         if (fit < 1) fit = 1;
     }
@@ -954,7 +972,7 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
     CK(c, hipMemsetAsync(c->d_queue, 0, 8 * sizeof(uint32_t), c->stream));
     CK(c, hipMemsetAsync(c->d_counters, 0, (size_t)ptd::kCounterWords * sizeof(unsigned long long), c->stream));
     CK(c, hipEventRecord(c->ev0, c->stream));
-    { Range range("acgpt: render megakernel (launch_batch)"); CK(c, ptd::launch_render(variant, a, grid, c->stream)); }
+    { Range range("acgpt: render megakernel (launch_batch)"); CK(c, ptd::launch_render(variant, c->math_mode, a, grid, c->stream)); }
     CK(c, hipEventRecord(c->ev1, c->stream));
     { Range range("acgpt: k_finalize"); CK(c, ptd::launch_finalize(a, c->stream)); }
     unsigned long long h[8], h_tail[2] = {0, 0};
@@ -977,6 +995,7 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
     c->stats.shade_lane_rounds = h[7];
     c->stats.grid_blocks = grid;
     c->stats.variant = (uint32_t)variant;
+    c->stats.math_mode = (uint32_t)(c->math_mode != 0 && ptd::render_variant_has_fast_math(variant) ? PT_MATH_FAST : PT_MATH_IEEE);
     c->stats.kernel_ms = ms;
     c->stats.launch_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return 0;
@@ -1089,8 +1108,10 @@ PT_API int pt_bench_traversal(pt_ctx* c, const float* rays, size_t n, int repeat
 // in / out sizes per element, in dwords (op 1: in = {seed, count}, out = 2 * count)
 PT_API int pt_selftest(pt_ctx* c, int op, const void* in, size_t n, void* out)
 {
-    static const int in_dw[20] = {2, 2, 3, 10, 10, 10, 10, 10, 10, 7, 4, 1, 6, 4, 2, 2, 6, 7, 3, 17}, out_dw[20] = {1, 0, 1, 3, 3, 3, 3, 3, 3, 4, 2, 4, 3, 3, 3, 3, 3, 3, 1, 3};
-    if (!c || !in || !out || op < 0 || op > 19 || n == 0 || n > (1u << 24)) return fail(c, "pt_selftest: bad argument");
+    //                            0  1  2   3   4   5   6   7   8  9 10 11 12 13 14 15 16 17 18  19  20 .. 29 unused           30 31 32 33 34 35 36 37 38
+    static const int in_dw[39] = {2, 2, 3, 10, 10, 10, 10, 10, 10, 7, 4, 1, 6, 4, 2, 2, 6, 7, 3, 17, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 1, 6, 4, 2, 2, 6, 7, 3},
+                     out_dw[39] = {1, 0, 1, 3, 3, 3, 3, 3, 3, 4, 2, 4, 3, 3, 3, 3, 3, 3, 1, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 3, 3, 3, 3, 3, 3, 1};
+    if (!c || !in || !out || op < 0 || op > 38 || in_dw[op] == 0 || n == 0 || n > (1u << 24)) return fail(c, "pt_selftest: bad argument");
     CK(c, hipSetDevice(c->device));
     size_t in_bytes = n * (size_t)in_dw[op] * 4, out_bytes = n * (size_t)out_dw[op] * 4;
     uint32_t launch_n = (uint32_t)n;

@@ -120,6 +120,27 @@ __device__ __forceinline__ f3 cross(const f3& a, const f3& b)
 { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 __device__ __forceinline__ float length(const f3& v) { return sqrtf(dot(v, v)); }
 __device__ __forceinline__ f3 normalize(const f3& v) { float invLen = 1.0f / sqrtf(dot(v, v)); return v * invLen; }
+// Arithmetic level of the shading code (template parameter FM of the functions below and of pt_shading.h):
+//   0  IEEE: correctly rounded division and square root, OCML sincosf / acosf — the level the CPU oracle is written at;
+//   1  level 0 with the cosine sampler's trigonometry on v_sin_f32 / v_cos_f32 and sqrt(1 - z1) for sin(acos(sqrt(z1)));
+//   2  what nvcc --use_fast_math makes of the reference's own build (CMakeLists.txt:267: -prec-div=false -prec-sqrt=false,
+//      sinf -> __sinf, cosf -> __cosf): a / b = a * v_rcp_f32(b), v_sqrt_f32, v_rsq_f32, v_sin_f32 / v_cos_f32 (1 ulp each).
+// Traversal and the triangle test are the same at every level (hits stay bit-exact); only shading values move in their last bits.
+template <int FM> __device__ __forceinline__ float m_div(float a, float b) { return FM >= 2 ? a * __builtin_amdgcn_rcpf(b) : a / b; }
+template <int FM> __device__ __forceinline__ float m_sqrt(float x) { return FM >= 2 ? __builtin_amdgcn_sqrtf(x) : sqrtf(x); }
+template <int FM> __device__ __forceinline__ float m_length(const f3& v) { return m_sqrt<FM>(dot(v, v)); }
+template <int FM> __device__ __forceinline__ f3 m_normalize(const f3& v)
+{
+    if (FM >= 2) return v * __builtin_amdgcn_rsqf(dot(v, v));
+    const float invLen = 1.0f / sqrtf(dot(v, v));
+    return v * invLen;
+}
+// sin and cos of 2 pi u, u in [0, 1): the hardware instructions take their argument in revolutions
+template <int FM> __device__ __forceinline__ void m_sincos_2pi(float u, float& s, float& c)
+{
+    if (FM >= 2) { s = __builtin_amdgcn_sinf(u); c = __builtin_amdgcn_cosf(u); }
+    else sincosf(2.0f * kPIf * u, &s, &c);
+}
 __device__ __forceinline__ f3 reflect(const f3& i, const f3& n) { return i - 2.0f * n * dot(n, i); }
 __device__ __forceinline__ f3 faceforward(const f3& n, const f3& i, const f3& nref) { return n * copysignf(1.0f, dot(i, nref)); }
 __device__ __forceinline__ f3 lerp3(const f3& a, const f3& b, float t) { return a + t * (b - a); }

@@ -24,12 +24,13 @@ __device__ __forceinline__ void sample_pixel(int num_gpus, int width, int gpu_id
 
 // ---- sampling / BSDF pieces, restated from pathTracerPrograms.cu ---------------------
 // OrthonormalBasis :54-85
+template <int FM = 0>
 __device__ __forceinline__ void onb_transform(const f3& n, f3& p)
 {
     f3 bn;
     if (fabsf(n.x) > fabsf(n.z)) bn = mk(-n.y, n.x, 0.0f);
     else                         bn = mk(0.0f, -n.z, n.y);
-    bn = normalize(bn);
+    bn = m_normalize<FM>(bn);
     const f3 tg = cross(bn, n);
     p = p.x * tg + p.y * bn + p.z * n;
 }
@@ -45,75 +46,90 @@ __device__ __forceinline__ f3 cosine_sample_hemisphere(float eta1, float eta2)
     sincosf(phi, &sp, &cp);
     return mk(st * cp, st * sp, ct);
 }
-// the same sampler with v_sin_f32 / v_cos_f32 and sqrt(1 - z1) for sin(acos(sqrt(z1))): kernel variant 10 only
+// the same sampler with v_sin_f32 / v_cos_f32 and sqrt(1 - z1) for sin(acos(sqrt(z1))): arithmetic levels 1 and 2 (pt_device.h)
+template <int FM>
 __device__ __forceinline__ f3 cosine_sample_hemisphere_fast(float eta1, float eta2)
 {
-    const float ct = sqrtf(eta1), stt = sqrtf(1.0f - eta1);
+    const float ct = m_sqrt<FM>(eta1), stt = m_sqrt<FM>(1.0f - eta1);
     return mk(stt * __builtin_amdgcn_cosf(eta2), stt * __builtin_amdgcn_sinf(eta2), ct);
 }
 // uniform_sample_hemisphere :368-380 (the theta computed at :372 is unused there)
+template <int FM = 0>
 __device__ __forceinline__ f3 uniform_sample_hemisphere(float u1, float u2)
 {
-    const float phi = 2.0f * kPIf * u2;
     float sp, cp;
-    sincosf(phi, &sp, &cp);
-    return mk(cp * sqrtf(1 - u1 * u1), sp * sqrtf(1 - u1 * u1), u1);
+    m_sincos_2pi<FM>(u2, sp, cp);                                    // phi = 2 pi u2
+    return mk(cp * m_sqrt<FM>(1 - u1 * u1), sp * m_sqrt<FM>(1 - u1 * u1), u1);
 }
 // sampleGGX :455-476 (roughness is the literal 0.2 of :880)
+template <int FM = 0>
 __device__ __forceinline__ f3 sample_ggx(float u1, float u2, float roughness, const f3& N)
 {
-    const float phi = 2.0f * kPIf * u1;
-    const float cosTheta = sqrtf((1.0f - u2) / (1.0f + (roughness * roughness - 1.0f) * u2));
-    const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+    const float cosTheta = m_sqrt<FM>(m_div<FM>(1.0f - u2, 1.0f + (roughness * roughness - 1.0f) * u2));
+    const float sinTheta = m_sqrt<FM>(1.0f - cosTheta * cosTheta);
     float sp, cp;
-    sincosf(phi, &sp, &cp);                  // the values of sinf(phi), cosf(phi) with one argument reduction (see shade_hit)
+    m_sincos_2pi<FM>(u1, sp, cp);            // phi = 2 pi u1: the values of sinf(phi), cosf(phi) with one argument reduction (see shade_hit)
     const f3 H = mk(sinTheta * cp, sinTheta * sp, cosTheta);
     // :470 compares in double against 0.999; 0.999f rounds up, so the float test is identical
     const f3 up = fabsf(N.z) < 0.999f ? mk(0.0f, 0.0f, 1.0f) : mk(1.0f, 0.0f, 0.0f);
-    const f3 tangent = normalize(cross(up, N));
+    const f3 tangent = m_normalize<FM>(cross(up, N));
     const f3 bitangent = cross(N, tangent);
-    return normalize(H.x * tangent + H.y * bitangent + H.z * N);
+    return m_normalize<FM>(H.x * tangent + H.y * bitangent + H.z * N);
 }
 // fresnelSchlickConductor :494-510
+template <int FM = 0>
 __device__ __forceinline__ f3 fresnel_conductor(float cosTheta, const f3& eta, const f3& k)
 {
     const f3 eta2 = eta * eta, k2 = k * k;
     const f3 c2 = mk(cosTheta * cosTheta);
     const f3 t1 = eta2 - k2 - c2;
-    const f3 a2plusb2 = mk(sqrtf(t1.x * t1.x + 4 * eta2.x * k2.x), sqrtf(t1.y * t1.y + 4 * eta2.y * k2.y),
-                           sqrtf(t1.z * t1.z + 4 * eta2.z * k2.z));
+    const f3 a2plusb2 = mk(m_sqrt<FM>(t1.x * t1.x + 4 * eta2.x * k2.x), m_sqrt<FM>(t1.y * t1.y + 4 * eta2.y * k2.y),
+                           m_sqrt<FM>(t1.z * t1.z + 4 * eta2.z * k2.z));
     const f3 t2 = a2plusb2 + c2;
-    const f3 Rs = (t2 - 2 * eta * cosTheta + c2) / (t2 + 2 * eta * cosTheta + c2);
-    const f3 Rp = Rs * (t2 - 2 * eta * cosTheta + mk(1.0f)) / (t2 + 2 * eta * cosTheta + mk(1.0f));
+    const f3 rs_n = t2 - 2 * eta * cosTheta + c2, rs_d = t2 + 2 * eta * cosTheta + c2;
+    const f3 Rs = mk(m_div<FM>(rs_n.x, rs_d.x), m_div<FM>(rs_n.y, rs_d.y), m_div<FM>(rs_n.z, rs_d.z));
+    const f3 rp_n = Rs * (t2 - 2 * eta * cosTheta + mk(1.0f)), rp_d = t2 + 2 * eta * cosTheta + mk(1.0f);
+    const f3 Rp = mk(m_div<FM>(rp_n.x, rp_d.x), m_div<FM>(rp_n.y, rp_d.y), m_div<FM>(rp_n.z, rp_d.z));
     return (Rs + Rp) * 0.5f;
 }
 // FrDielectric :534-559
+template <int FM = 0>
 __device__ __forceinline__ float fr_dielectric(float cosThetaI, float etaI, float etaT)
 {
     cosThetaI = clampf(cosThetaI, -1.0f, 1.0f);
     if (!(cosThetaI > 0.0f)) { const float t = etaI; etaI = etaT; etaT = t; cosThetaI = fabsf(cosThetaI); }
-    const float sinThetaI = sqrtf(fmaxf(0.0f, 1.0f - cosThetaI * cosThetaI));
-    const float sinThetaT = etaI / etaT * sinThetaI;
+    const float sinThetaI = m_sqrt<FM>(fmaxf(0.0f, 1.0f - cosThetaI * cosThetaI));
+    const float sinThetaT = m_div<FM>(etaI, etaT) * sinThetaI;
     if (sinThetaT >= 1.0f) return 1.0f;
-    const float cosThetaT = sqrtf(fmaxf(0.0f, 1.0f - sinThetaT * sinThetaT));
-    const float rParl = ((etaT * cosThetaI) - (etaI * cosThetaT)) / ((etaT * cosThetaI) + (etaI * cosThetaT));
-    const float rPerp = ((etaI * cosThetaI) - (etaT * cosThetaT)) / ((etaI * cosThetaI) + (etaT * cosThetaT));
+    const float cosThetaT = m_sqrt<FM>(fmaxf(0.0f, 1.0f - sinThetaT * sinThetaT));
+    const float rParl = m_div<FM>((etaT * cosThetaI) - (etaI * cosThetaT), (etaT * cosThetaI) + (etaI * cosThetaT));
+    const float rPerp = m_div<FM>((etaI * cosThetaI) - (etaT * cosThetaT), (etaI * cosThetaI) + (etaT * cosThetaT));
     return (rParl * rParl + rPerp * rPerp) / 2.0f;
 }
 // refract, cuda/helpers.h:107-137
+template <int FM = 0>
 __device__ __forceinline__ bool refract_dir(f3& r, const f3& i, const f3& n, float ior)
 {
     f3 nn = n;
     float negNdotV = dot(i, nn);
     float eta;
     if (negNdotV > 0.0f) { eta = ior; nn = -n; negNdotV = -negNdotV; }
-    else                 { eta = 1.f / ior; }
+    else                 { eta = m_div<FM>(1.f, ior); }
     const float k = 1.f - eta * eta * (1.f - negNdotV * negNdotV);
     if (k < 0.0f) { r = mk(0.f); return false; }
-    r = normalize(eta * i - (eta * negNdotV + sqrtf(k)) * nn);
+    r = m_normalize<FM>(eta * i - (eta * negNdotV + m_sqrt<FM>(k)) * nn);
     return true;
 }
-__device__ __forceinline__ float safe_div(float a, float b) { return b == 0.0f ? 0.0f : a / b; }
+template <int FM = 0>
+__device__ __forceinline__ float safe_div(float a, float b) { return b == 0.0f ? 0.0f : m_div<FM>(a, b); }
+// Throughput of a path that survives the roulette (:771-777: each component safeDivide'd by the survival probability); at the
+// fast arithmetic level the three quotients share one reciprocal
+template <int FM = 0>
+__device__ __forceinline__ f3 roulette_scale(const f3& att, float p)
+{
+    if (FM >= 2) { const float ip = p == 0.0f ? 0.0f : __builtin_amdgcn_rcpf(p); return att * ip; }
+    return mk(safe_div(att.x, p), safe_div(att.y, p), safe_div(att.z, p));
+}
 
 // make_color, cuda/helpers.h:35-62
 __device__ __forceinline__ float to_srgb1(float c)
@@ -158,12 +174,12 @@ struct Pending {
 
 // __closesthit__diffuse__ch, pathTracerPrograms.cu:866-1031, for one lane.  Returns true when a
 // shadow ray (P, L, 0.01, Ldist - 0.01) has to be traced before the segment can be accounted.
-// TRIG_DIAG (kernel variant 10, opt-in): the cosine-weighted sampler with v_sin_f32 / v_cos_f32 and sqrt(1 - z1) for
-// sin(acos(sqrt(z1))) — the kind of arithmetic the reference's own build uses (nvcc --use_fast_math, CMakeLists.txt:267).
-// Different low bits than the default path, same image within the parity tolerance (test_fast_math_variant).
+// FM: arithmetic level (pt_device.h): 0 IEEE, 1 the cosine sampler's trigonometry in hardware, 2 the arithmetic of the reference's
+// own build (nvcc --use_fast_math, CMakeLists.txt:267).  Levels 1 and 2 give different low bits than level 0, the same image
+// within the parity tolerance (test_fast_math_variant).
 // FROM_RECORD: normal and material from the triangle record itself (`slot` indexes sc.tris; the four-wide experiment, whose
 // slots are positions in its own record array) instead of the builder's shading record
-template <bool TRIG_DIAG = false, bool FROM_RECORD = false, typename Late>
+template <int FM = 0, bool FROM_RECORD = false, typename Late>
 __device__ __forceinline__ bool shade_hit(const DeviceScene& sc, Late late, const f3& org, const f3& dir,
                                           float t_hit, int slot, int depth, uint32_t& pseed, f3& att, f3& emission,
                                           Pending& pd, f3& P, f3& L, float& Ldist)
@@ -191,32 +207,32 @@ __device__ __forceinline__ bool shade_hit(const DeviceScene& sc, Late late, cons
         const float z1 = rnd(s);
         const float z2 = rnd(s);
         f3 w_in;
-        if (late().useIS) w_in = TRIG_DIAG ? cosine_sample_hemisphere_fast(z1, z2) : cosine_sample_hemisphere(z1, z2);
-        else         w_in = uniform_sample_hemisphere(z1, z2);
-        onb_transform(N, w_in);
+        if (late().useIS) w_in = FM >= 1 ? cosine_sample_hemisphere_fast<FM>(z1, z2) : cosine_sample_hemisphere(z1, z2);
+        else         w_in = uniform_sample_hemisphere<FM>(z1, z2);
+        onb_transform<FM>(N, w_in);
         pd.nxt_dir = w_in;
         pd.nxt_org = P;
         att *= Kd;
     } else if (bsdf == PT_BSDF_METALLIC) {                                       // :931-953
         const float z1 = rnd(s);
         const float z2 = rnd(s);
-        const f3 mn = sample_ggx(z1, z2, 0.2f, N);
+        const f3 mn = sample_ggx<FM>(z1, z2, 0.2f, N);
         const f3 R = reflect(dir, mn);
         pd.nxt_dir = R;
         pd.nxt_org = P + R * 1e-4f;
         const f3 eta = mk(1.45f, 0.7f, 1.55f), kk = mk(3.0f, 2.2f, 3.5f);
         const float cosTheta = fmaxf(dot(mn, -dir), 0.0f);
-        const f3 F = fresnel_conductor(cosTheta, eta, kk);
+        const f3 F = fresnel_conductor<FM>(cosTheta, eta, kk);
         att *= F * Kd;
     } else if (bsdf == PT_BSDF_REFRACTION) {                                     // :954-982
-        const f3 inc = normalize(dir);
-        const float cos_theta = dot(normalize(-dir), N0);
-        const float F = fr_dielectric(cos_theta, 1.0f, IOR);
+        const f3 inc = m_normalize<FM>(dir);
+        const float cos_theta = dot(m_normalize<FM>(-dir), N0);
+        const float F = fr_dielectric<FM>(cos_theta, 1.0f, IOR);
         if (rnd(s) < F) {
             pd.nxt_dir = reflect(inc, N0);
         } else {
             f3 rd;
-            pd.nxt_dir = refract_dir(rd, inc, N0, IOR) ? rd : reflect(inc, N0);
+            pd.nxt_dir = refract_dir<FM>(rd, inc, N0, IOR) ? rd : reflect(inc, N0);
         }
         pd.nxt_org = P + pd.nxt_dir * 1e-3f;
         att *= Kd;
@@ -233,12 +249,12 @@ __device__ __forceinline__ bool shade_hit(const DeviceScene& sc, Late late, cons
     const auto& La = late();
     if (La.useDL && bsdf != PT_BSDF_REFRACTION) {                                // :1003-1026
         const f3 light_pos = mk(La.light.corner) + mk(La.light.v1) * z1 + mk(La.light.v2) * z2;
-        Ldist = length(light_pos - P);
-        L = normalize(light_pos - P);
+        Ldist = m_length<FM>(light_pos - P);
+        L = m_normalize<FM>(light_pos - P);
         const float nDl = dot(N, L);
         const float LnDl = -dot(mk(La.light.normal), L);
         want_shadow = nDl > 0.0f && LnDl > 0.0f;
-        pd.weight = nDl * LnDl * La.light_area / (kPIf * Ldist * Ldist);         // :1021-1022 (|v1 x v2| from the host), used only if unoccluded
+        pd.weight = m_div<FM>(nDl * LnDl * La.light_area, kPIf * Ldist * Ldist);         // :1021-1022 (|v1 x v2| from the host), used only if unoccluded
     }
     return want_shadow;
 }
@@ -251,7 +267,7 @@ __device__ __forceinline__ bool shade_hit(const DeviceScene& sc, Late late, cons
 // (pd.done), or, when the function returns true, only if the shadow ray (P, L, 0.01, Ldist - 0.01) is unoccluded.
 // att becomes the throughput of the continuation; prev_pdf the solid-angle pdf of the sampled direction where a
 // light sample was taken (0 elsewhere: a later emitter hit then counts in full).
-template <typename Late>
+template <int FM = 0, typename Late>
 __device__ __forceinline__ bool shade_hit_lights(const DeviceScene& sc, Late late, const f3& org, const f3& dir,
                                                  float t_hit, int slot, int depth, uint32_t& pseed, f3& att, float& prev_pdf,
                                                  Pending& pd, f3& P, f3& L, float& Ldist)
@@ -274,8 +290,8 @@ __device__ __forceinline__ bool shade_hit_lights(const DeviceScene& sc, Late lat
         float w = 1.0f;
         if (depth > 0 && prev_pdf > 0.0f) {
             const float cos_l = fabsf(dot(N0, dir));
-            const float p_l = (t_hit * t_hit) / (area_total * cos_l);
-            w = cos_l > 0.0f ? (prev_pdf * prev_pdf) / (prev_pdf * prev_pdf + p_l * p_l) : 1.0f;
+            const float p_l = m_div<FM>(t_hit * t_hit, area_total * cos_l);
+            w = cos_l > 0.0f ? m_div<FM>(prev_pdf * prev_pdf, prev_pdf * prev_pdf + p_l * p_l) : 1.0f;
         }
         pd.radiance = att * Ke * w;
         if (bsdf == PT_BSDF_REFRACTION) (void)rnd(s); else { (void)rnd(s); (void)rnd(s); }
@@ -290,32 +306,32 @@ __device__ __forceinline__ bool shade_hit_lights(const DeviceScene& sc, Late lat
     if (bsdf == PT_BSDF_DIFFUSE) {
         const float z1 = rnd(s);
         const float z2 = rnd(s);
-        f3 w_in = useIS ? cosine_sample_hemisphere(z1, z2) : uniform_sample_hemisphere(z1, z2);
+        f3 w_in = useIS ? (FM >= 1 ? cosine_sample_hemisphere_fast<FM>(z1, z2) : cosine_sample_hemisphere(z1, z2)) : uniform_sample_hemisphere<FM>(z1, z2);
         const float cos_out = w_in.z;
-        onb_transform(N, w_in);
+        onb_transform<FM>(N, w_in);
         pd.nxt_dir = w_in;
         pd.nxt_org = P;
-        if (useIS) { att = att_in * Kd; bsdf_pdf = cos_out / kPIf; }
+        if (useIS) { att = att_in * Kd; bsdf_pdf = FM >= 2 ? cos_out * (1.0f / kPIf) : cos_out / kPIf; }
         else       { att = att_in * Kd * (2.0f * cos_out); bsdf_pdf = 1.0f / (2.0f * kPIf); }
     } else if (bsdf == PT_BSDF_METALLIC) {
         const float z1 = rnd(s);
         const float z2 = rnd(s);
-        const f3 mn = sample_ggx(z1, z2, 0.2f, N);
+        const f3 mn = sample_ggx<FM>(z1, z2, 0.2f, N);
         const f3 R = reflect(dir, mn);
         pd.nxt_dir = R;
         pd.nxt_org = P + R * 1e-4f;
         const f3 eta = mk(1.45f, 0.7f, 1.55f), kk = mk(3.0f, 2.2f, 3.5f);
         const float cosTheta = fmaxf(dot(mn, -dir), 0.0f);
-        att = att_in * (fresnel_conductor(cosTheta, eta, kk) * Kd);
+        att = att_in * (fresnel_conductor<FM>(cosTheta, eta, kk) * Kd);
     } else if (bsdf == PT_BSDF_REFRACTION) {
-        const f3 inc = normalize(dir);
-        const float cos_theta = dot(normalize(-dir), N0);
-        const float F = fr_dielectric(cos_theta, 1.0f, mp->ior);
+        const f3 inc = m_normalize<FM>(dir);
+        const float cos_theta = dot(m_normalize<FM>(-dir), N0);
+        const float F = fr_dielectric<FM>(cos_theta, 1.0f, mp->ior);
         if (rnd(s) < F) {
             pd.nxt_dir = reflect(inc, N0);
         } else {
             f3 rd;
-            pd.nxt_dir = refract_dir(rd, inc, N0, mp->ior) ? rd : reflect(inc, N0);
+            pd.nxt_dir = refract_dir<FM>(rd, inc, N0, mp->ior) ? rd : reflect(inc, N0);
         }
         pd.nxt_org = P + pd.nxt_dir * 1e-3f;
         att = att_in * Kd;
@@ -331,21 +347,21 @@ __device__ __forceinline__ bool shade_hit_lights(const DeviceScene& sc, Late lat
         while (k + 1u < sc.n_lights && !(target < sc.lights[5u * k + 1u].w)) k++;
         const float4 l0 = sc.lights[5u * k], l1 = sc.lights[5u * k + 1u], l2 = sc.lights[5u * k + 2u], l3 = sc.lights[5u * k + 3u], l4 = sc.lights[5u * k + 4u];
         const float lo = k ? sc.lights[5u * (k - 1u) + 1u].w : 0.0f;
-        const float u = fminf(fmaxf((target - lo) / l0.w, 0.0f), 0.99999994f);
-        const float su = sqrtf(u);
+        const float u = fminf(fmaxf(m_div<FM>(target - lo, l0.w), 0.0f), 0.99999994f);
+        const float su = m_sqrt<FM>(u);
         const f3 light_pos = mk(l0.x, l0.y, l0.z) + mk(l1.x, l1.y, l1.z) * (su * (1.0f - z2)) + mk(l2.x, l2.y, l2.z) * (su * z2);
         const f3 Lv = light_pos - P;
         const float dist2 = dot(Lv, Lv);
-        Ldist = sqrtf(dist2);
-        L = Lv / Ldist;
+        Ldist = m_sqrt<FM>(dist2);
+        L = FM >= 2 ? Lv * __builtin_amdgcn_rsqf(dist2) : Lv / Ldist;
         const float nDl = dot(N, L);
         const float LnDl = fabsf(dot(mk(l3.x, l3.y, l3.z), L));
         prev_pdf = bsdf_pdf;
         want_shadow = nDl > 0.0f && LnDl > 0.0f;
-        const float p_l = dist2 / (area_total * LnDl);
-        const float p_b = useIS ? nDl / kPIf : 1.0f / (2.0f * kPIf);
-        const float w = (p_l * p_l) / (p_l * p_l + p_b * p_b);
-        const float geom = nDl * LnDl * area_total / (kPIf * dist2);
+        const float p_l = m_div<FM>(dist2, area_total * LnDl);
+        const float p_b = useIS ? (FM >= 2 ? nDl * (1.0f / kPIf) : nDl / kPIf) : 1.0f / (2.0f * kPIf);
+        const float w = m_div<FM>(p_l * p_l, p_l * p_l + p_b * p_b);
+        const float geom = m_div<FM>(nDl * LnDl * area_total, kPIf * dist2);
         if (want_shadow) pd.radiance = att_in * Kd * mk(l4.x, l4.y, l4.z) * (geom * w);      // counted only if the shadow ray finds nothing
     }
     return want_shadow;

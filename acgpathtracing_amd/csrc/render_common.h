@@ -313,10 +313,11 @@ __device__ __forceinline__ void finish_runs(const RenderArgs& A, QueueState& q, 
 }
 
 // Camera ray through pixel (px, py) with jitter (jx, jy), unnormalised (:730-737)
+template <int FM = 0>
 __device__ __forceinline__ f3 camera_dir(float px, float py, float jx, float jy, float fw, float fh, const f3& U, const f3& V, const f3& W)
 {
-    const float dx = 2.0f * ((px + jx) / fw) - 1.0f;
-    const float dy = 2.0f * ((py + jy) / fh) - 1.0f;
+    const float dx = 2.0f * m_div<FM>(px + jx, fw) - 1.0f;
+    const float dy = 2.0f * m_div<FM>(py + jy, fh) - 1.0f;
     return dx * U + dy * V + W;
 }
 // Can a ray from the eye along D (any length) reach the scene's bounding box?  elo / ehi: box corners minus the eye, the box
@@ -342,7 +343,7 @@ __device__ __forceinline__ uint32_t opaque_zero() { uint32_t z; asm volatile("s_
 // ---- host-side interface of the kernel translation units --------------------------------------------------------------------
 typedef void (*RenderKernel)(const RenderArgsBox);
 // workgroup-level wavefront kernels (render_wavefront.hip)
-struct WfDesc { RenderKernel k; int nt, ns, pool, stack_cap; const char* name; const char* kernel; };
+struct WfDesc { RenderKernel k; int nt, ns, pool, stack_cap; const char* name; const char* kernel; RenderKernel k_fast; const char* kernel_fast; };
 int wf_variant_count();
 const WfDesc* wf_variant(int i);
 size_t wf_lds_bytes(const WfDesc& d, uint32_t stack_entries);

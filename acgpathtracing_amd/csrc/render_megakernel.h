@@ -78,13 +78,14 @@ struct RenderArgs {
 
 int render_variant_count();
 const char* render_variant_name(int variant);
-const char* render_variant_kernel(int variant);   // the instantiation as a kernel trace prints it ("" for experiment variants)
+const char* render_variant_kernel(int variant, int math);   // the instantiation as a kernel trace prints it ("" for experiment variants); math: pt_set_math_mode
+int render_variant_has_fast_math(int variant);   // 0: the variant exists with IEEE arithmetic only (experiment rows)
 int render_variant_threads(int variant);
 int render_variant_top_nodes(int variant);      // > 0: the variant stages that many nodes of the tree's top in LDS (experiments)
 int render_variant_stack_cap(int variant);      // 0 = the whole stack in LDS
 int render_variant_node_format(int variant);   // 0 fp32 two-child; 7 / 8 / 9 fp16 two-child (min-max / rotated / rotated, flags in the multipliers); experiments: 1/2/4 16-bit grid, 3 four-wide 8-bit
-hipError_t render_occupancy(int variant, uint32_t stack_entries, uint32_t n_nodes, int* blocks_per_cu);
-hipError_t launch_render(int variant, const RenderArgs& args, uint32_t grid_blocks, hipStream_t stream);
+hipError_t render_occupancy(int variant, int math, uint32_t stack_entries, uint32_t n_nodes, int* blocks_per_cu);
+hipError_t launch_render(int variant, int math, const RenderArgs& args, uint32_t grid_blocks, hipStream_t stream);
 hipError_t launch_finalize(const RenderArgs& args, hipStream_t stream);
 hipError_t launch_resolve(const float4* accum, uint32_t* fb, uint32_t n, hipStream_t stream);
 hipError_t launch_keep_owned(float4* accum, uint32_t width, uint32_t height, int rank, int world, hipStream_t stream);

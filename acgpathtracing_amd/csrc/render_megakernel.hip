@@ -54,9 +54,11 @@ __global__ void __launch_bounds__(kFinThreads) k_finalize(const RenderArgs A)
 // Variant 0: segment-synchronous.  Every iteration: all live lanes trace one radiance segment to
 // completion, shade, (some) trace a shadow ray, account.  Simple; lanes wait for the slowest ray.
 // =================================================================================================
+template <int MATH>
 __global__ void __launch_bounds__(kRenderThreads)
 k_render(const RenderArgsBox B)
 {
+    constexpr int FM = MATH ? 2 : 0;                  // arithmetic level of the shading code (pt_device.h)
     const RenderArgs& A = B.a[0];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -95,7 +97,7 @@ k_render(const RenderArgsBox B)
         if (lp.alive && lp.new_path) {                                // camera path start, :727-745
             const float jx = rnd(lp.seed);
             const float jy = rnd(lp.seed);
-            dir = normalize(camera_dir((float)(lp.pxy & 0xFFFFu), (float)(lp.pxy >> 16), jx, jy, fw, fh, camU, camV, camW));
+            dir = m_normalize<FM>(camera_dir<FM>((float)(lp.pxy & 0xFFFFu), (float)(lp.pxy >> 16), jx, jy, fw, fh, camU, camV, camW));
             org = eye;
             att = mk(1.0f);
             pseed = lp.seed;
@@ -113,7 +115,7 @@ k_render(const RenderArgsBox B)
         pd.done = true;                                               // __miss__ms :833-847
         bool want_shadow = false;
         if (lp.alive && hit.slot >= 0)
-            want_shadow = shade_hit(sc, late, org, dir, hit.t, hit.slot, depth, pseed, att, emission, pd, P, L, Ldist);
+            want_shadow = shade_hit<FM>(sc, late, org, dir, hit.t, hit.slot, depth, pseed, att, emission, pd, P, L, Ldist);
 
         const unsigned long long shadow_mask = vote(want_shadow);
         if (shadow_mask != 0ull) {                                    // traceOcclusion :651-684
@@ -131,7 +133,7 @@ k_render(const RenderArgsBox B)
             const bool rr = rnd(pseed) > p;
             end = pd.done || rr || (uint32_t)depth >= A.maxDepth;
             if (!end) {
-                att = mk(safe_div(att.x, p), safe_div(att.y, p), safe_div(att.z, p));
+                att = roulette_scale<FM>(att, p);
                 org = pd.nxt_org;
                 dir = pd.nxt_dir;
                 ++depth;
@@ -211,12 +213,15 @@ __device__ __forceinline__ void setup_ray(const f3& ro, const f3& rd, const QGri
 //               fits beside the lane stacks; 1024-thread workgroups so one copy serves 16 waves)
 //           3 = four-wide tree, 8-bit child boxes, 48-byte records shared with the triangles (wide_bvh.hip):
 //               3 loads per visit and about half the visits; the stack holds {base, child list} groups
-// DIAG (timing experiments only, never a product variant): 1 = 12 extra dependent VALU per inner
-// step, 2 = two extra 16-byte loads per inner step.
+// DIAG: 1 = 12 extra dependent VALU per inner step, 2 = two extra 16-byte loads per inner step (timing experiments only, never
+// a product variant); 3 = arithmetic level 1 of the shading code (pt_device.h, FM: the cosine sampler's trigonometry in hardware).
+// MATH (pt_set_math_mode): 0 = IEEE arithmetic in the shading code, the level the CPU oracle is written at; 1 = the arithmetic of
+// the reference's own build (nvcc --use_fast_math, CMakeLists.txt:267; level 2 of pt_device.h).  Traversal and triangle test are
+// the same in both: the rays that are traced for a given path prefix, and what they hit, do not depend on it.
 // INNER: 0 = stack entirely in LDS, nested branches; 1 = stack top cached in a register (the LDS read of
 // a pop is consumed one push/pop later, off the critical path) and child selection by selects; 2, 3 = the same with
 // that many node visits per trip through the loop control.
-template <int SHADE_K, int LEAF_K, int NODE_FMT, int THREADS, int MINW, bool STATS, int DIAG = 0, int INNER = 0, int LEAVES = 1, bool LIGHTS = false, int STACK_CAP = 0, int TOPN = 0>
+template <int SHADE_K, int LEAF_K, int NODE_FMT, int THREADS, int MINW, bool STATS, int DIAG = 0, int INNER = 0, int LEAVES = 1, bool LIGHTS = false, int STACK_CAP = 0, int TOPN = 0, int MATH = 0>
 __global__ void __launch_bounds__(THREADS, MINW)
 k_render_pw(const RenderArgsBox B)
 {
@@ -232,6 +237,7 @@ k_render_pw(const RenderArgsBox B)
     // dozen pending nodes).  Any tree depth at a fixed LDS cost, and none of the per-access test that made the capped
     // kernel 10 % slower than the plain one on the same tree.
     constexpr bool WINDOW = STACK_CAP < 0;
+    constexpr int FM = MATH ? 2 : (DIAG == 3 ? 1 : 0);         // arithmetic level of the shade phase
     constexpr int WIN = WINDOW ? -STACK_CAP : 0;
     static_assert(!WINDOW || ((WIN & (WIN - 1)) == 0 && WIN >= 16), "the window wraps by masking and must hold two trips");
     const uint32_t lds_entries = WINDOW ? (uint32_t)WIN + 1u : ((STACK_CAP > 0 && A.stack_entries > (uint32_t)STACK_CAP) ? (uint32_t)STACK_CAP : A.stack_entries);   // WINDOW: entry WIN of a lane's column holds its window base
@@ -343,8 +349,8 @@ k_render_pw(const RenderArgsBox B)
                 bool want_shadow = false;
                 f3 P, L; float Ldist;
                 if (best_slot >= 0) {
-                    if (LIGHTS) want_shadow = shade_hit_lights(sc, late, ro, rd, best_t, best_slot, depth, pseed, att, prev_pdf, pd, P, L, Ldist);
-                    else want_shadow = shade_hit<DIAG == 3, NODE_FMT == 3>(sc, late, ro, rd, best_t, best_slot, depth, pseed, att, emission, pd, P, L, Ldist);
+                    if (LIGHTS) want_shadow = shade_hit_lights<FM>(sc, late, ro, rd, best_t, best_slot, depth, pseed, att, prev_pdf, pd, P, L, Ldist);
+                    else want_shadow = shade_hit<FM, NODE_FMT == 3>(sc, late, ro, rd, best_t, best_slot, depth, pseed, att, emission, pd, P, L, Ldist);
                 } else {                                              // __miss__ms :833-847
                     pd.radiance = mk(0.0f); pd.weight = 0.0f; pd.done = true;
                 }
@@ -376,7 +382,7 @@ k_render_pw(const RenderArgsBox B)
             const bool rr = rnd(pseed) > p;
             end = pd.done || rr || (uint32_t)depth >= A.maxDepth;
             if (!end) {
-                att = mk(safe_div(att.x, p), safe_div(att.y, p), safe_div(att.z, p));
+                att = roulette_scale<FM>(att, p);
                 ro = pd.nxt_org; rd = pd.nxt_dir;
                 ++depth;
             } else {
@@ -415,7 +421,7 @@ k_render_pw(const RenderArgsBox B)
             for (;;) {
                 const float jx = rnd(lp.seed);
                 const float jy = rnd(lp.seed);
-                D = camera_dir((float)(lp.pxy & 0xFFFFu), (float)(lp.pxy >> 16), jx, jy, fw, fh, camU, camV, camW);
+                D = camera_dir<FM>((float)(lp.pxy & 0xFFFFu), (float)(lp.pxy >> 16), jx, jy, fw, fh, camU, camV, camW);
                 // a camera ray that cannot reach the scene box: one radiance segment that misses (:833-847 adds nothing to
                 // the result, done = true); its path ends here and the lane goes on to its next sample
                 if ((lp.tag & (1u << 24)) != 0u || reaches_scene(D, elo, ehi)) break;      // bit 24: every ray of this pixel reaches the box
@@ -424,7 +430,7 @@ k_render_pw(const RenderArgsBox B)
                 if (lp.samples_left == 0u) { lp.alive = false; fin_pending = true; break; }
             }
             if (lp.alive) {
-                rd = normalize(D);
+                rd = m_normalize<FM>(D);
                 ro = eye;
                 att = mk(1.0f);
                 pseed = lp.seed;
@@ -1138,7 +1144,9 @@ hipError_t trace_stream_occupancy(int fmt, uint32_t stack_entries, int* blocks_p
 }
 
 // ---- host-side launchers ------------------------------------------------------------------
-struct VariantDesc { RenderKernel k; int threads; int node_fmt; const char* name; int stack_cap = 0; const char* kernel = ""; int wf = -1; int top_n = 0; };   // wf >= 0: index into render_wavefront.hip's table
+// k / kernel: the instantiation with IEEE arithmetic in the shading code; k_fast / kernel_fast: its twin with the arithmetic of the
+// reference's own build (pt_set_math_mode; nullptr: the variant exists at the IEEE level only — experiment rows)
+struct VariantDesc { RenderKernel k; int threads; int node_fmt; const char* name; int stack_cap = 0; const char* kernel = ""; int wf = -1; int top_n = 0; RenderKernel k_fast = nullptr; const char* kernel_fast = ""; };   // wf >= 0: index into render_wavefront.hip's table
 
 // Render kernel variants.  0: segment-synchronous (fp32 nodes).  Others: persistent traversal
 // <SHADE_K, LEAF_K, NODE_FMT, THREADS, MINW, STATS, DIAG, INNER, LEAVES, LIGHTS, STACK_CAP, TOPN>.  The product library carries the
@@ -1148,17 +1156,19 @@ struct VariantDesc { RenderKernel k; int threads; int node_fmt; const char* name
 // can be tied to the variant that ran (pt_variant_kernel, bench.py).
 #define PW(...) k_render_pw<__VA_ARGS__>
 #define PWN(...) "k_render_pw<" #__VA_ARGS__ ">"
+// a product row: the twelve arguments once, the IEEE instantiation (MATH 0) and its fast-math twin (MATH 1) from them
+#define ROW(threads, fmt, name, cap, ...) {PW(__VA_ARGS__, 0), threads, fmt, name, cap, PWN(__VA_ARGS__, 0), -1, 0, PW(__VA_ARGS__, 1), PWN(__VA_ARGS__, 1)}
 static const VariantDesc kVariants[] = {
-    {k_render, 256, 0, "sync fp32-nodes", 0, "k_render"},
-    {PW(44, 16, 0, 256, 4, false, 0, 2, 2, false, 0, 0), 256, 0, "pw K44 L16 fp32 nodes w4, register stack top, two visits and two triangle tests per loop trip", 0, PWN(44, 16, 0, 256, 4, false, 0, 2, 2, false, 0, 0)},
-    {PW(44, 16, 0, 256, 4, true, 0, 2, 2, false, 0, 0), 256, 0, "pw K44 L16 fp32 nodes + scheduler stats", 0, PWN(44, 16, 0, 256, 4, true, 0, 2, 2, false, 0, 0)},
-    {PW(48, 8, 0, 256, 4, false, 0, 2, 1, false, 0, 0), 256, 0, "pw K48 L8 fp32 nodes w4, two visits per loop trip (large scenes whose fp16 planes would be too coarse)", 0, PWN(48, 8, 0, 256, 4, false, 0, 2, 1, false, 0, 0)},
-    {PW(48, 12, 0, 256, 4, false, 3, 1, 1, false, 0, 0), 256, 0, "FAST-MATH hardware sin/cos + algebraic acos in the cosine-weighted sampler (opt-in; other bits than the default)", 0, PWN(48, 12, 0, 256, 4, false, 3, 1, 1, false, 0, 0)},
-    {PW(44, 16, 8, 256, 4, false, 0, 3, 2, false, 0, 0), 256, 8, "pw K44 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes, w4, three visits and two triangle tests per loop trip", 0, PWN(44, 16, 8, 256, 4, false, 0, 3, 2, false, 0, 0)},
-    {PW(44, 16, 9, 256, 4, true, 0, 5, 2, false, 0, 0), 256, 9, "pw K44 L16 fp16 sign-rotated nodes, five visits per trip + scheduler stats (the default kernel's loop at four waves)", 0, PWN(44, 16, 9, 256, 4, true, 0, 5, 2, false, 0, 0)},
-    {PW(40, 16, 9, 256, 5, false, 0, 5, 2, false, 0, 0), 256, 9, "pw K40 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes with the rotate amounts in the multipliers' low bits, FIVE waves per SIMD (96 registers), five visits and two triangle tests per loop trip", 0, PWN(40, 16, 9, 256, 5, false, 0, 5, 2, false, 0, 0)},
-    {PW(44, 16, 9, 256, 4, false, 0, 5, 2, true, 0, 0), 256, 9, "LIGHTS scene-driven area lights + MIS (light mode 1, opt-in: not the reference's estimator), fp16 sign-rotated nodes w4", 0, PWN(44, 16, 9, 256, 4, false, 0, 5, 2, true, 0, 0)},
-    {PW(24, 16, 9, 256, 5, false, 0, 5, 2, false, -16, 0), 256, 9, "pw K24 L16 fp16 sign-rotated nodes, five waves per SIMD, for large scenes and deep trees: shade rounds at 24 parked lanes (rays are long there), a sliding window of 16 stack entries per lane in LDS, deeper ones moved to global memory four at a time", -16, PWN(24, 16, 9, 256, 5, false, 0, 5, 2, false, -16, 0)},
+    {k_render<0>, 256, 0, "sync fp32-nodes", 0, "k_render<0>", -1, 0, k_render<1>, "k_render<1>"},
+    ROW(256, 0, "pw K44 L16 fp32 nodes w4, register stack top, two visits and two triangle tests per loop trip", 0, 44, 16, 0, 256, 4, false, 0, 2, 2, false, 0, 0),
+    ROW(256, 0, "pw K44 L16 fp32 nodes + scheduler stats", 0, 44, 16, 0, 256, 4, true, 0, 2, 2, false, 0, 0),
+    ROW(256, 0, "pw K48 L8 fp32 nodes w4, two visits per loop trip (large scenes whose fp16 planes would be too coarse)", 0, 48, 8, 0, 256, 4, false, 0, 2, 1, false, 0, 0),
+    ROW(256, 0, "TRIG fp32 nodes w4 with the cosine sampler's sin / cos / acos on v_sin_f32 / v_cos_f32 / sqrt (IEEE mode: everything else IEEE; other bits than its neighbours there)", 0, 48, 12, 0, 256, 4, false, 3, 1, 1, false, 0, 0),
+    ROW(256, 8, "pw K44 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes, w4, three visits and two triangle tests per loop trip", 0, 44, 16, 8, 256, 4, false, 0, 3, 2, false, 0, 0),
+    ROW(256, 9, "pw K44 L16 fp16 sign-rotated nodes, five visits per trip + scheduler stats (the default kernel's loop at four waves)", 0, 44, 16, 9, 256, 4, true, 0, 5, 2, false, 0, 0),
+    ROW(256, 9, "pw K40 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes with the rotate amounts in the multipliers' low bits, FIVE waves per SIMD (96 registers), five visits and two triangle tests per loop trip", 0, 40, 16, 9, 256, 5, false, 0, 5, 2, false, 0, 0),
+    ROW(256, 9, "LIGHTS scene-driven area lights + MIS (light mode 1, opt-in: not the reference's estimator), fp16 sign-rotated nodes w4", 0, 44, 16, 9, 256, 4, false, 0, 5, 2, true, 0, 0),
+    ROW(256, 9, "pw K24 L16 fp16 sign-rotated nodes, five waves per SIMD, for large scenes and deep trees: shade rounds at 24 parked lanes (rays are long there), a sliding window of 16 stack entries per lane in LDS, deeper ones moved to global memory four at a time", -16, 24, 16, 9, 256, 5, false, 0, 5, 2, false, -16, 0),
     {nullptr, 0, 9, nullptr, 0, nullptr, 0},      // kVariantWf: filled from render_wavefront.hip's table (variant_desc)
     {nullptr, 0, 9, nullptr, 0, nullptr, 1},      // kVariantWfStats
 #ifdef ACGPT_EXPERIMENTS
@@ -1173,15 +1183,24 @@ static VariantDesc variant_desc(int v)
     if (d.wf >= 0) {
         const WfDesc* w = wf_variant(d.wf);
         d.k = w->k; d.threads = (w->nt + w->ns) * 64; d.name = w->name; d.stack_cap = w->stack_cap; d.kernel = w->kernel;
+        d.k_fast = w->k_fast; d.kernel_fast = w->kernel_fast;
     }
     return d;
 }
+// the instantiation a math mode runs: the fast twin where the variant has one (experiment rows exist at the IEEE level only)
+static RenderKernel variant_kernel(const VariantDesc& d, int math) { return (math != 0 && d.k_fast != nullptr) ? d.k_fast : d.k; }
 const char* render_variant_name(int v) { return (v >= 0 && v < render_variant_count()) ? variant_desc(v).name : "?"; }
 int render_variant_node_format(int v) { return (v >= 0 && v < render_variant_count()) ? kVariants[v].node_fmt : -1; }
 int render_variant_threads(int v) { return (v >= 0 && v < render_variant_count()) ? variant_desc(v).threads : 0; }
 int render_variant_stack_cap(int v) { return (v >= 0 && v < render_variant_count()) ? variant_desc(v).stack_cap : 0; }
 int render_variant_top_nodes(int v) { return (v >= 0 && v < render_variant_count()) ? kVariants[v].top_n : 0; }
-const char* render_variant_kernel(int v) { return (v >= 0 && v < render_variant_count()) ? variant_desc(v).kernel : ""; }
+const char* render_variant_kernel(int v, int math)
+{
+    if (v < 0 || v >= render_variant_count()) return "";
+    const VariantDesc d = variant_desc(v);
+    return (math != 0 && d.k_fast != nullptr) ? d.kernel_fast : d.kernel;
+}
+int render_variant_has_fast_math(int v) { return (v >= 0 && v < render_variant_count()) ? variant_desc(v).k_fast != nullptr : 0; }
 
 static size_t variant_lds(const VariantDesc& d, uint32_t stack_entries, uint32_t n_nodes)
 {
@@ -1193,10 +1212,11 @@ static size_t variant_lds(const VariantDesc& d, uint32_t stack_entries, uint32_t
     return lds;
 }
 
-hipError_t render_occupancy(int variant, uint32_t stack_entries, uint32_t n_nodes, int* blocks_per_cu)
+hipError_t render_occupancy(int variant, int math, uint32_t stack_entries, uint32_t n_nodes, int* blocks_per_cu)
 {
     if (variant < 0 || variant >= render_variant_count()) return hipErrorInvalidValue;
-    const VariantDesc d = variant_desc(variant);
+    VariantDesc d = variant_desc(variant);
+    d.k = variant_kernel(d, math);
     const size_t lds = variant_lds(d, stack_entries, n_nodes);
     *blocks_per_cu = 0;
     if (lds > 160u * 1024u) return hipSuccess;      // does not fit: 0 blocks, caller reports it
@@ -1205,10 +1225,11 @@ hipError_t render_occupancy(int variant, uint32_t stack_entries, uint32_t n_node
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, (const void*)d.k, d.threads, lds);
 }
 
-hipError_t launch_render(int variant, const RenderArgs& args, uint32_t grid_blocks, hipStream_t stream)
+hipError_t launch_render(int variant, int math, const RenderArgs& args, uint32_t grid_blocks, hipStream_t stream)
 {
     if (variant < 0 || variant >= render_variant_count()) return hipErrorInvalidValue;
-    const VariantDesc d = variant_desc(variant);
+    VariantDesc d = variant_desc(variant);
+    d.k = variant_kernel(d, math);
     const size_t lds = variant_lds(d, args.stack_entries, args.n_lds_nodes);
     RenderArgsBox box;
     box.a[0] = args;

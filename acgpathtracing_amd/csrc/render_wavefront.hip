@@ -242,10 +242,11 @@ __device__ __forceinline__ void wf_refill(const RenderArgs& A, QueueState& q, ui
 // stack in LDS (deeper ones in global memory); a trace wave exchanges records when FETCH_K lanes are idle; triangle rounds at
 // LEAF_K lanes; VISITS node visits per trip through the loop control.  fp16 nodes (HNode, the slab test of NODE_FMT 9).
 // =================================================================================================================================
-template <int NT, int NS, int POOL, int STACK_CAP, int FETCH_K, int LEAF_K, int VISITS, int MINB, bool DIAG>
+template <int NT, int NS, int POOL, int STACK_CAP, int FETCH_K, int LEAF_K, int VISITS, int MINB, bool DIAG, int MATH = 0>
 __global__ void __launch_bounds__((NT + NS) * 64, MINB)
 k_render_wf(const RenderArgsBox B)
 {
+    constexpr int FM = MATH ? 2 : 0;                  // arithmetic level of the shading code (pt_device.h; pt_set_math_mode)
     constexpr int THREADS = (NT + NS) * 64;
     constexpr uint32_t FOLD = (uint32_t)((NT * 64 + POOL + 64 + 3) & ~3);
     static_assert((POOL & (POOL - 1)) == 0, "ring indices wrap by masking");
@@ -495,13 +496,13 @@ k_render_wf(const RenderArgsBox B)
                         for (;;) {
                             const float jx = rnd(lp.seed);
                             const float jy = rnd(lp.seed);
-                            D = camera_dir((float)(lp.pxy & 0xFFFFu), (float)(lp.pxy >> 16), jx, jy, fw, fh, camU, camV, camW);
+                            D = camera_dir<FM>((float)(lp.pxy & 0xFFFFu), (float)(lp.pxy >> 16), jx, jy, fw, fh, camU, camV, camW);
                             if (reaches_scene(D, elo, ehi)) break;
                             my_culled++;
                             lp.samples_left--;
                             if (lp.samples_left == 0u) { lp.alive = false; finished = true; break; }
                         }
-                        if (lp.alive) { rd = normalize(D); ro = eye; lp.new_path = false; }
+                        if (lp.alive) { rd = m_normalize<FM>(D); ro = eye; lp.new_path = false; }
                     }
                     if (vote(my_culled != 0u) != 0ull) {
                         unsigned long long sum = 0ull;
@@ -593,7 +594,7 @@ k_render_wf(const RenderArgsBox B)
                     f3 P, L; float Ldist;
                     f3 emission = mk(0.0f);
                     if (hit >= 0) {
-                        want_shadow = shade_hit<false, false>(late().scene, late, ro, rd, tmax, hit, depth, pseed, att, emission, pd, P, L, Ldist);
+                        want_shadow = shade_hit<FM, false>(late().scene, late, ro, rd, tmax, hit, depth, pseed, att, emission, pd, P, L, Ldist);
                     } else {                                              // __miss__ms :833-847
                         pd.radiance = mk(0.0f); pd.weight = 0.0f; pd.done = true;
                     }
@@ -619,7 +620,7 @@ k_render_wf(const RenderArgsBox B)
                 const bool rr = rnd(pseed) > p;
                 end = pd.done || rr || (uint32_t)depth >= late().maxDepth;
                 if (!end) {
-                    att = mk(safe_div(att.x, p), safe_div(att.y, p), safe_div(att.z, p));
+                    att = roulette_scale<FM>(att, p);
                     ro = pd.nxt_org; rd = pd.nxt_dir;
                     ++depth;
                     start_radiance = true;
@@ -640,14 +641,14 @@ k_render_wf(const RenderArgsBox B)
                 for (;;) {
                     const float jx = rnd(lseed);
                     const float jy = rnd(lseed);
-                    D = camera_dir((float)(pxy & 0xFFFFu), (float)(pxy >> 16), jx, jy, fw, fh, camU, camV, camW);
+                    D = camera_dir<FM>((float)(pxy & 0xFFFFu), (float)(pxy >> 16), jx, jy, fw, fh, camU, camV, camW);
                     if (reaches_scene(D, elo, ehi)) break;
                     my_culled++;
                     samples_left--;
                     if (samples_left == 0u) { finished = true; break; }
                 }
                 if (!finished) {
-                    rd = normalize(D);
+                    rd = m_normalize<FM>(D);
                     ro = eye;
                     att = mk(1.0f);
                     pseed = lseed;
@@ -712,12 +713,12 @@ k_render_wf(const RenderArgsBox B)
 #define WF(...) k_render_wf<__VA_ARGS__>
 #define WFN(...) "k_render_wf<" #__VA_ARGS__ ">"
 static const WfDesc kWfVariants[] = {
-    {WF(12, 4, 512, 16, 16, 16, 5, 1, false), 12, 4, 512, 16, "wavefront: 12 trace + 4 shade waves per workgroup, 512 record slots in LDS, fp16 nodes, one workgroup per CU (a measured experiment: never chosen automatically)", WFN(12, 4, 512, 16, 16, 16, 5, 1, false)},
-    {WF(12, 4, 512, 16, 16, 16, 5, 1, true), 12, 4, 512, 16, "wavefront 12 + 4 with per-role time stamps (pt_debug_wf)", WFN(12, 4, 512, 16, 16, 16, 5, 1, true)},
+    {WF(12, 4, 512, 16, 16, 16, 5, 1, false, 0), 12, 4, 512, 16, "wavefront: 12 trace + 4 shade waves per workgroup, 512 record slots in LDS, fp16 nodes, one workgroup per CU (a measured experiment: never chosen automatically)", WFN(12, 4, 512, 16, 16, 16, 5, 1, false, 0), WF(12, 4, 512, 16, 16, 16, 5, 1, false, 1), WFN(12, 4, 512, 16, 16, 16, 5, 1, false, 1)},
+    {WF(12, 4, 512, 16, 16, 16, 5, 1, true, 0), 12, 4, 512, 16, "wavefront 12 + 4 with per-role time stamps (pt_debug_wf)", WFN(12, 4, 512, 16, 16, 16, 5, 1, true, 0), WF(12, 4, 512, 16, 16, 16, 5, 1, true, 1), WFN(12, 4, 512, 16, 16, 16, 5, 1, true, 1)},
 #ifdef ACGPT_EXPERIMENTS
-    {WF(8, 2, 256, 16, 16, 16, 5, 2, false), 8, 2, 256, 16, "wavefront: 8 trace + 2 shade waves per workgroup, 256 record slots, fp16 nodes, two workgroups per CU (five waves per SIMD)", WFN(8, 2, 256, 16, 16, 16, 5, 2, false)},
-    {WF(8, 8, 512, 16, 16, 16, 5, 1, true), 8, 8, 512, 16, "wavefront 8 + 8 with per-role time stamps", WFN(8, 8, 512, 16, 16, 16, 5, 1, true)},
-    {WF(10, 6, 512, 16, 16, 16, 5, 1, true), 10, 6, 512, 16, "wavefront 10 + 6 with per-role time stamps", WFN(10, 6, 512, 16, 16, 16, 5, 1, true)},
+    {WF(8, 2, 256, 16, 16, 16, 5, 2, false, 0), 8, 2, 256, 16, "wavefront: 8 trace + 2 shade waves per workgroup, 256 record slots, fp16 nodes, two workgroups per CU (five waves per SIMD)", WFN(8, 2, 256, 16, 16, 16, 5, 2, false, 0), WF(8, 2, 256, 16, 16, 16, 5, 2, false, 1), WFN(8, 2, 256, 16, 16, 16, 5, 2, false, 1)},
+    {WF(8, 8, 512, 16, 16, 16, 5, 1, true, 0), 8, 8, 512, 16, "wavefront 8 + 8 with per-role time stamps", WFN(8, 8, 512, 16, 16, 16, 5, 1, true, 0), WF(8, 8, 512, 16, 16, 16, 5, 1, true, 1), WFN(8, 8, 512, 16, 16, 16, 5, 1, true, 1)},
+    {WF(10, 6, 512, 16, 16, 16, 5, 1, true, 0), 10, 6, 512, 16, "wavefront 10 + 6 with per-role time stamps", WFN(10, 6, 512, 16, 16, 16, 5, 1, true, 0), WF(10, 6, 512, 16, 16, 16, 5, 1, true, 1), WFN(10, 6, 512, 16, 16, 16, 5, 1, true, 1)},
 #endif
 };
 int wf_variant_count() { return (int)(sizeof(kWfVariants) / sizeof(kWfVariants[0])); }

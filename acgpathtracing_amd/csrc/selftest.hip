@@ -71,6 +71,36 @@ __global__ void k_selftest(int op, const uint32_t* __restrict__ in, uint32_t n, 
         fout[3 * i] = o.x; fout[3 * i + 1] = o.y; fout[3 * i + 2] = o.z;
         return;
     }
+    if (op >= 32 && op <= 38) {                      // ops 12..18 at the arithmetic level of PT_MATH_FAST (pt_device.h, level 2): same records
+        const int base = op - 20;
+        const int in_w = (base == 12 || base == 16) ? 6 : base == 13 ? 4 : base == 17 ? 7 : base == 18 ? 3 : 2;
+        const float* r = fin + in_w * i;
+        f3 o = mk(0.0f);
+        switch (base) {
+            case 12: o = mk(r[3], r[4], r[5]); onb_transform<2>(mk(r[0], r[1], r[2]), o); break;
+            case 13: o = roulette_scale<2>(mk(r[0], r[1], r[2]), r[3]); break;
+            case 14: o = cosine_sample_hemisphere_fast<2>(r[0], r[1]); break;
+            case 15: o = uniform_sample_hemisphere<2>(r[0], r[1]); break;
+            case 16: o = sample_ggx<2>(r[0], r[1], r[2], mk(r[3], r[4], r[5])); break;
+            case 17: o = fresnel_conductor<2>(r[0], mk(r[1], r[2], r[3]), mk(r[4], r[5], r[6])); break;
+            default: fout[i] = fr_dielectric<2>(r[0], r[1], r[2]); return;
+        }
+        fout[3 * i] = o.x; fout[3 * i + 1] = o.y; fout[3 * i + 2] = o.z;
+        return;
+    }
+    if (op == 30) {                                  // the primitives of PT_MATH_FAST: in a, b; out a / b, sqrt(|a|), normalize((a, b, 1)).x, .y
+        const float a = fin[2 * i], b = fin[2 * i + 1];
+        const f3 nv = m_normalize<2>(mk(a, b, 1.0f));
+        fout[4 * i] = m_div<2>(a, b); fout[4 * i + 1] = m_sqrt<2>(fabsf(a)); fout[4 * i + 2] = nv.x; fout[4 * i + 3] = nv.y;
+        return;
+    }
+    if (op == 31) {                                  // in u in [0, 1); out sin(2 pi u), cos(2 pi u) at level 2 (v_sin_f32 / v_cos_f32), then at level 0
+        float sv, cv, s0, c0;
+        m_sincos_2pi<2>(fin[i], sv, cv);
+        m_sincos_2pi<0>(fin[i], s0, c0);
+        fout[4 * i] = sv; fout[4 * i + 1] = cv; fout[4 * i + 2] = s0; fout[4 * i + 3] = c0;
+        return;
+    }
     if (op == 19) {
         // the default kernel's box test end to end: in = ray o xyz, d xyz, box lo xyz, hi xyz (fp32, as the builder holds it),
         // scene centre xyz, inv_scale (a power of two), tmax; out = accepted (n <= min(f, tmax)), n, f.  The box goes through

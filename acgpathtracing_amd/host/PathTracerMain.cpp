@@ -209,7 +209,7 @@ int main(int argc, char** argv)
     std::string objfilepath, out = "frame.png", keys, save_accum, restore_accum;
     int32_t width = 512, height = 512, frames = 8, dump_every = 0;
     bool zero_copy = false;
-    int orbit_dx = 0, orbit_dy = 0, zoom_steps = 0, sample_chunks = 0, build_mode = 1, fuse = 1, light_mode = 0;
+    int orbit_dx = 0, orbit_dy = 0, zoom_steps = 0, sample_chunks = 0, build_mode = 1, fuse = 1, light_mode = 0, math_mode = PT_MATH_FAST;
     PathTracerState state;
     state.params.useDirectLighting = false;
     state.params.useImportanceSampling = false;
@@ -239,6 +239,7 @@ int main(int argc, char** argv)
         else if (a == "--sample-chunks") sample_chunks = atoi(next());
         else if (a == "--build-mode") build_mode = atoi(next());
         else if (a == "--fuse-frames") fuse = std::min(64, std::max(1, atoi(next())));
+        else if (a == "--math") { const std::string m = next(); math_mode = (m == "ieee" || m == "0") ? PT_MATH_IEEE : PT_MATH_FAST; }   // fast: the arithmetic of the reference's own build (nvcc --use_fast_math); ieee: the CPU oracle's
         else if (a == "--light-mode") light_mode = atoi(next());      // 0 = the reference's hard-coded rectangle (:154-158), 1 = the OBJ's emissive triangles + MIS
         else { std::cerr << "unknown option " << a << std::endl; return 2; }
     }
@@ -274,6 +275,7 @@ int main(int argc, char** argv)
         PT_CHECK(state.context, pt_set_build_mode(state.context, build_mode));
         PT_CHECK(state.context, pt_set_sample_chunks(state.context, sample_chunks));
         PT_CHECK(state.context, pt_set_light_mode(state.context, light_mode));
+        PT_CHECK(state.context, pt_set_math_mode(state.context, math_mode));
         buildTheAccelarationStructure(state, obj);
         std::cout << "Acceleration Structure Built" << std::endl;
         createModule(state);

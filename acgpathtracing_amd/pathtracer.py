@@ -341,6 +341,15 @@ def setLightMode(state, mode):
     state.refreshAccumulationBuffer = True
 
 
+def setMathMode(state, mode):
+    """Arithmetic of the shading code (include/acgpt.h pt_set_math_mode).  "fast" / 1 (the default): what the reference's own build
+    computes with (nvcc --use_fast_math, CMakeLists.txt:267): approximate reciprocal, square root, sine and cosine.  "ieee" / 0:
+    correctly rounded division and square root and the C library's sincosf / acosf, the level the CPU oracle is written at."""
+    m = {"ieee": _native.MATH_IEEE, "fast": _native.MATH_FAST}.get(mode, mode)
+    _check(state.context, _native.hip().pt_set_math_mode(state.context, int(m)), "pt_set_math_mode")
+    state.refreshAccumulationBuffer = True
+
+
 def getStats(state):
     s = Stats()
     _check(state.context, _native.hip().pt_get_stats(state.context, C.byref(s)), "pt_get_stats")
@@ -427,8 +436,9 @@ def CleanAllTheThings(state):
 
 
 def setup(obj_path, width=512, height=512, max_depth=4, direct_lighting=False, importance_sampling=False,
-          spp=samples_per_launch, device_id=0, build_mode=None, device_ids=None):
-    """The body of main() up to the frame loop (PathTracerMain.cpp:650-684) as one call."""
+          spp=samples_per_launch, device_id=0, build_mode=None, device_ids=None, math_mode=None):
+    """The body of main() up to the frame loop (PathTracerMain.cpp:650-684) as one call.  math_mode: None (the library's default,
+    "fast"), "ieee" or "fast" (setMathMode)."""
     obj = TinyObjWrapper(obj_path)
     if not obj.dataLoaded:
         raise PathTracerError("cannot load %s: %s" % (obj_path, obj.error))
@@ -450,4 +460,6 @@ def setup(obj_path, width=512, height=512, max_depth=4, direct_lighting=False, i
     createShaderBindingTable(state, obj)
     initializeTheLaunch(state)
     state.params.samplesPerPixel = int(spp)
+    if math_mode is not None:
+        setMathMode(state, math_mode)
     return state, obj

@@ -78,6 +78,9 @@ def parse():
     ap.add_argument("--cpu-spp", type=int, default=0, help="samples per pixel of the CPU baseline sample (0 = per config)")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--variant", type=int, default=-1, help="render kernel variant (-1 = library default)")
+    ap.add_argument("--math", default="fast", choices=["fast", "ieee"],
+                    help="arithmetic of the shading code (pt_set_math_mode): fast = what the reference's own build uses (nvcc --use_fast_math, the library default); ieee = the CPU oracle's level")
+    ap.add_argument("--no-ieee-leg", action="store_true", help="skip the untimed launches in the other math mode that the report quotes beside the timed one (N = 1 only)")
     ap.add_argument("--fuse", type=int, default=8, help="steps per kernel launch (pt_launch_frames); 1 = one launch per step")
     ap.add_argument("--chunks", type=int, default=0, help="sample runs per pixel (pt_set_sample_chunks); 0 = automatic")
     ap.add_argument("--save", default="", help="write the final framebuffer as PPM (rank 0)")
@@ -293,6 +296,8 @@ def main():
     assert L.pt_set_stream(state.context, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
     if a.blocks_per_cu or a.variant >= 0:
         assert L.pt_set_tuning(state.context, a.blocks_per_cu, a.variant if a.variant >= 0 else -1) == 0
+    math_mode = _native.MATH_FAST if a.math == "fast" else _native.MATH_IEEE
+    assert L.pt_set_math_mode(state.context, math_mode) == 0
     info = pt.getBvhInfo(state)
 
     fuse = max(1, min(a.fuse, 64, a.steps))
@@ -347,13 +352,28 @@ def main():
     tot_rays, tot_shadow, tot_paths, tot_culled = D.sum_over_ranks([rays, shadow, paths, culled], cdev)
     if a.variant >= 0:
         assert int(last_stats.variant) == a.variant, "the kernel variant that ran is not the one requested"
+    assert int(last_stats.math_mode) == math_mode, "the math mode that ran is not the one requested"
+    # the other math mode, untimed, beside the timed one: two launches of the timed shape, the second one's kernel time (N = 1 only)
+    other_math = None
+    if world == 1 and not a.no_ieee_leg:
+        other = _native.MATH_IEEE if math_mode == _native.MATH_FAST else _native.MATH_FAST
+        assert L.pt_set_math_mode(state.context, other) == 0
+        keep, keep_fb = accum.clone(), fb.clone()
+        launch(0, fuse)
+        so = launch(0, fuse)
+        accum.copy_(keep); fb.copy_(keep_fb)
+        assert L.pt_set_math_mode(state.context, math_mode) == 0
+        o_rays = int(so.radiance_rays) + int(so.shadow_rays)
+        other_math = {"math": "ieee" if other == _native.MATH_IEEE else "fast", "kernel": (L.pt_variant_kernel(int(so.variant), other) or b"").decode(),
+                      "kernel_ms_per_step": float(so.kernel_ms) / fuse, "Mray_per_s_kernel_time": o_rays / (float(so.kernel_ms) * 1e-3) / 1e6,
+                      "note": "untimed: kernel time of one %d-step launch in the other math mode, HIP events" % fuse}
 
     # ---- report ---------------------------------------------------------------------------------------
     if rank == 0:
         all_rays = tot_rays + tot_shadow
         n_launches = max(1, len(kernel_ms))
         vname = L.pt_variant_name(int(last_stats.variant))
-        vkern = L.pt_variant_kernel(int(last_stats.variant))
+        vkern = L.pt_variant_kernel(int(last_stats.variant), int(last_stats.math_mode))
         roof = roofline_block(a, info, world, fuse, kernel_ms, (rays + shadow - culled) / n_launches, (rays + shadow) / n_launches, a.steps / n_launches,
                               vname.decode() if vname else "?", vkern.decode() if vkern else "", L.pt_kernel_source_hash().decode())
         miss = primary_miss_fraction(p, info)
@@ -373,6 +393,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s (%d triangles), %dx%d, %d spp per step x %d steps, maxDepth %d, importance sampling + direct lighting"
                                    % (a.scene, info.n_tris, a.width, a.height, a.spp, a.steps, a.max_depth),
+                       "math": ("fast: the arithmetic of the reference's own build (nvcc --use_fast_math, CMakeLists.txt:267): v_rcp / v_sqrt / v_rsq / v_sin / v_cos in the shading code; traversal and triangle test as in ieee mode"
+                                if math_mode == _native.MATH_FAST else "ieee: correctly rounded division / square root and libm sincosf / acosf in the shading code (the CPU oracle's level)"),
                        "steps_per_kernel_launch": fuse, "kernel_launches": n_launches,
                        "parallelism": "pixel tiles 8x4 over %d GPU(s)%s" % (world, ", RCCL reduce of float4 accumulation" if world > 1 else ""),
                        "rays": int(all_rays), "paths": int(tot_paths), "rays_per_path": all_rays / max(1.0, tot_paths),
@@ -382,6 +404,8 @@ def main():
                        "bvh": {"nodes": info.n_nodes, "max_depth": info.max_depth, "stack_entries": info.stack_entries, "build_ms": info.build_ms}},
             "roofline": roof,
         }
+        if other_math:
+            out["other_math_mode"] = other_math
         if world == 1 and not a.no_cpu_baseline:
             base, _ = cpu_baseline(pt, obj, p, a.cpu_spp)
             out["cpu_baseline"] = base

@@ -104,6 +104,8 @@ typedef struct pt_stats {
     uint64_t shade_lane_rounds; /* ... times lanes shaded in them              */
     uint64_t culled_rays;       /* camera rays that end at the scene's bounding box without a traversal: one radiance
                                  * segment that misses (pathTracerPrograms.cu:833-847); counted in radiance_rays and paths too */
+    uint32_t math_mode;         /* arithmetic of the shading code this launch ran with (pt_set_math_mode)        */
+    uint32_t reserved;
 } pt_stats;
 
 /* What the on-device LBVH build produced. */
@@ -209,6 +211,20 @@ int pt_resolve_framebuffer(pt_ctx* ctx, const float* accumulation_rgba, uint8_t*
  *      the same image.  Same random draws per segment as mode 0.  One kernel variant serves it (pt_variant_name "LIGHTS").  */
 int pt_set_light_mode(pt_ctx* ctx, int mode);
 
+/* Arithmetic of the shading code (closest-hit, samplers, light sample, roulette, camera-ray set-up).
+ *   PT_MATH_FAST (default): the arithmetic of the reference's own build.  /root/reference/CMakeLists.txt:267 compiles
+ *      pathTracerPrograms.cu with nvcc --use_fast_math (-prec-div=false -prec-sqrt=false, sinf -> __sinf, cosf -> __cosf):
+ *      a / b is a * rcp(b), sqrtf / 1 / sqrtf are the approximate instructions, sin / cos of 2 pi u the hardware ones.  Here:
+ *      v_rcp_f32, v_sqrt_f32, v_rsq_f32, v_sin_f32, v_cos_f32 (1 ulp each) and sqrt(1 - z) for sin(acos(sqrt(z))).
+ *   PT_MATH_IEEE: correctly rounded division and square root, the C library's sincosf / acosf — the level the CPU oracle
+ *      (oracle/oracle_pt.cpp) is written at; the mode in which most pixels of an image equal the oracle's bit for bit.
+ * BVH traversal and the triangle test are the same code in both modes (hit triangle and distance of a given ray are bit-exact
+ * either way); the modes differ in the last bits of shading values, i.e. by less than the parity tolerance (image MSE < 1e-6
+ * against the oracle in both; tests/test_gpu_parity.py).  Every kernel variant of the product library exists in both modes. */
+#define PT_MATH_IEEE 0
+#define PT_MATH_FAST 1
+int pt_set_math_mode(pt_ctx* ctx, int mode);
+
 /* Sample chunks (1, 2, 4, 8, 16, 32; 0 = automatic, the default: 8 runs per pixel, 16 when this rank
  * holds fewer than 2^20 pixels, reduced until every run keeps at least 4 samples).  With c > 1 a pixel's samplesPerPixel samples are cut into
  * c consecutive runs, each owned by its own lane with the PRNG skipped ahead to where the run
@@ -228,9 +244,10 @@ int pt_set_tuning(pt_ctx* ctx, int blocks_per_cu, int variant);
  * are timing experiments (some deliberately compute different bits) and are never selected by default; "FAST-MATH" and
  * "LIGHTS" (the kernel of pt_set_light_mode(1)) are opt-in and compute other bits than the reference's estimator. */
 const char* pt_variant_name(int variant);
-/* The variant's kernel as a kernel trace prints it ("k_render_pw<44, 16, 9, 256, 5, false, 0, 5, 2, false, 0>"), and a hash
- * of the kernel sources this library was built from: what bench.py checks a committed profile against before quoting it. */
-const char* pt_variant_kernel(int variant);
+/* The variant's kernel in a math mode as a kernel trace prints it ("k_render_pw<40, 16, 9, 256, 5, false, 0, 5, 2, false, 0, 0, 1>":
+ * the last argument is the math mode), and a hash of the kernel sources this library was built from: what bench.py checks a
+ * committed profile against before quoting it. */
+const char* pt_variant_kernel(int variant, int math_mode);
 const char* pt_kernel_source_hash(void);
 
 /* Stream the launches are enqueued on (a hipStream_t, e.g. torch's current

@@ -45,7 +45,12 @@ int pt_bench_traversal(pt_ctx* ctx, const float* rays, size_t n, int repeats, in
  *   op 19 fp16 slab test: box -> outward fp16 planes, ray -> per-axis multiplier / addend with the rotate flags in the
  *         multiplier's low bits, entry / exit distance          in float[n][17] = ray o, d, box lo, hi, scene centre, inv_scale
  *         (a power of two), tmax    out uint32[n][3] = accepted, entry t (float bits), exit t (float bits).  Must accept every
- *         ray that meets the box shrunk by the builder's pad (tests/test_gpu_golden.py).                                       */
+ *         ray that meets the box shrunk by the builder's pad (tests/test_gpu_golden.py).
+ * the arithmetic of PT_MATH_FAST (pt_set_math_mode; no reference vectors exist for it: nvcc's approximate instructions are not
+ * reproducible here — the ops are held against their IEEE twins by error bounds):
+ *   op 30 primitives      in float[n][2] = a, b     out float[n][4] = a * rcp(b), sqrt(|a|), x and y of normalize((a, b, 1))
+ *   op 31 sin / cos of 2 pi u                       in float[n]     out float[n][4] = v_sin_f32(u), v_cos_f32(u), sinf(2 pi u), cosf(2 pi u)
+ *   op 32..38 = ops 12..18 at that level, same records (op 33: the roulette's throughput scaling, one reciprocal for the three quotients) */
 int pt_selftest(pt_ctx* ctx, int op, const void* in, size_t n, void* out);
 /* Diagnostic: after a launch of a "+ scheduler stats" kernel variant, three 100 MHz stamps per wave (start,
  * first time it found the work queue empty, end; 0 = wave did not run), HOST output of 3 * max_waves values. */

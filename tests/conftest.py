@@ -34,10 +34,12 @@ def gpu_state_factory():
     import acgpathtracing_amd as pt
     made = []
 
-    def make(obj_path, sample_chunks=1, **kw):
-        """sample_chunks=1: the reference's own summation order (what most parity tests want)."""
+    def make(obj_path, sample_chunks=1, math_mode="ieee", **kw):
+        """sample_chunks=1: the reference's own summation order; math_mode="ieee": the arithmetic level the oracle is written
+        at (what most parity tests want: bits comparable with the oracle's).  The library's default, "fast" — the arithmetic of
+        the reference's own --use_fast_math build — is held against the oracle by tolerance in the tests that name it."""
         from acgpathtracing_amd import _native
-        state, obj = pt.setup(obj_path, **kw)
+        state, obj = pt.setup(obj_path, math_mode=math_mode, **kw)
         made.append(state)
         assert _native.hip().pt_set_sample_chunks(state.context, sample_chunks) == 0
         return state, obj

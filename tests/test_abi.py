@@ -39,8 +39,8 @@ def test_exports_every_declared_symbol(lib):
     out = subprocess.run(["nm", "-D", "--defined-only", _native.hip_library_path()], capture_output=True, text=True, check=True).stdout
     exported = set(re.findall(r" T (pt_[a-z_]+)", out))
     assert exported == set(syms) | set(hooks)
-    assert lib.pt_abi_version() == 2 == _native.ABI_VERSION
-    assert C.sizeof(_native.Stats) == 88 and C.sizeof(_native.BvhInfo) == 80
+    assert lib.pt_abi_version() == 3 == _native.ABI_VERSION
+    assert C.sizeof(_native.Stats) == 96 and C.sizeof(_native.BvhInfo) == 80
 
 
 def test_pod_layouts_match_the_reference():
@@ -93,7 +93,7 @@ def test_render_kernels_keep_their_occupancy_budget(lib):
     for k in rows:
         args = [a.strip() for a in re.search(r"k_render_pw<([^>]*)>", k["name"]).group(1).split(",")]
         (five if args[4] == "5" else four).append((k, args))
-    assert len(five) == 2, [k["name"] for k, _ in five]
+    assert len(five) == 4, [k["name"] for k, _ in five]      # each in both math modes
     for k, args in five:            # the default and its large-scene twin (windowed stack): nothing in scratch memory
         assert k["vgpr_count"] <= 96, k
         assert k["vgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
@@ -102,8 +102,9 @@ def test_render_kernels_keep_their_occupancy_budget(lib):
 
 
 def test_variant_kernel_names_are_the_code_objects(lib):
-    """pt_variant_kernel(v) is what bench.py holds a committed profile against: it must be, character for character, the name
-    a kernel trace prints for that variant's instantiation — i.e. a kernel that exists in the built code object."""
+    """pt_variant_kernel(v, math mode) is what bench.py holds a committed profile against: it must be, character for character,
+    the name a kernel trace prints for that variant's instantiation — i.e. a kernel that exists in the built code object; and the
+    two math modes of a variant are two different kernels."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import kernel_meta
@@ -112,10 +113,12 @@ def test_variant_kernel_names_are_the_code_objects(lib):
     for v in range(64):
         if lib.pt_variant_name(v) is None:
             break
-        kern = lib.pt_variant_kernel(v).decode()
-        assert kern, "variant %d has no kernel name" % v
-        hits = [x for x in names if ("ptd::" + kern + "(") in x]
-        assert len(hits) == 1, (v, kern, [x for x in names if kern.split("<")[0] in x][:3])
+        kerns = [lib.pt_variant_kernel(v, m).decode() for m in (_native.MATH_IEEE, _native.MATH_FAST)]
+        assert kerns[0] != kerns[1], (v, kerns)
+        for kern in kerns:
+            assert kern, "variant %d has no kernel name" % v
+            hits = [x for x in names if ("ptd::" + kern + "(") in x]
+            assert len(hits) == 1, (v, kern, [x for x in names if kern.split("<")[0] in x][:3])
         n += 1
     assert n >= 10
     assert re.fullmatch(r"[0-9a-f]{16}", lib.pt_kernel_source_hash().decode())

@@ -152,6 +152,72 @@ def test_gpu_ptprog_math(ctx):
               (name, 100 * (d[ok] == 0).mean(), 100 * (d[ok] > 2).mean(), absd[ok].max()))
 
 
+def test_gpu_fast_math_error_bounds(ctx):
+    """PT_MATH_FAST (pt_set_math_mode, the library's default): the shading helpers with v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 /
+    v_sin_f32 / v_cos_f32 — the kind of arithmetic nvcc --use_fast_math gives the reference's own build
+    (/root/reference/CMakeLists.txt:267).  nvcc's approximate instructions cannot be reproduced here, so there are no golden
+    vectors for this level; it is held against the SAME reference vectors as the IEEE level (test_gpu_ptprog_math), by error
+    bounds: each approximate instruction is within 1 ulp, a quotient a * rcp(b) within 2, and the helpers' results stay
+    within a few 1e-7 of the reference's values (components of unit vectors, Fresnel terms in [0, 1])."""
+    n = G["math_onb_n"].shape[0]
+    cat = lambda *cols: np.concatenate([np.asarray(c, np.float32).reshape(n, -1) for c in cols], axis=1)
+    rng = np.random.default_rng(31)
+    # primitives (op 30): a / b, sqrt(|a|), normalize((a, b, 1)) against float64
+    m = 1 << 18
+    a = (rng.standard_normal(m) * np.exp(rng.uniform(-20, 20, m))).astype(np.float32)
+    b = (rng.standard_normal(m) * np.exp(rng.uniform(-20, 20, m))).astype(np.float32)
+    b[b == 0] = 1.0
+    got = run(ctx, 30, np.stack([a, b], axis=1), m, np.zeros((m, 4), np.float32))
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    q = (a64 / b64).astype(np.float32)
+    ok = np.isfinite(q) & (np.abs(q) > 1e-30) & (np.abs(b) > 1e-30) & (np.abs(b) < 1e30)       # denormal reciprocals / quotients: out of the shading code's range
+    assert ulp_distance(got[ok, 0], q[ok]).max() <= 2.0, ulp_distance(got[ok, 0], q[ok]).max()
+    r = np.sqrt(np.abs(a64)).astype(np.float32)
+    assert ulp_distance(got[:, 1], r).max() <= 1.0
+    ln = np.sqrt(a64 * a64 + b64 * b64 + 1.0)
+    fin = np.isfinite(a64 * a64 + b64 * b64) & (a64 * a64 + b64 * b64 < 1e37)
+    assert np.abs(got[fin, 2] - a64[fin] / ln[fin]).max() <= 3e-7 and np.abs(got[fin, 3] - b64[fin] / ln[fin]).max() <= 3e-7
+    # sin / cos of 2 pi u (op 31): the hardware instructions against float64, and the IEEE-level pair beside them
+    u = np.concatenate([rng.random(m - 4).astype(np.float32), np.array([0.0, 0.25, 0.5, 0.99999994], np.float32)])
+    got = run(ctx, 31, u, m, np.zeros((m, 4), np.float32))
+    ang = 2.0 * np.pi * u.astype(np.float64)
+    hw = max(np.abs(got[:, 0] - np.sin(ang)).max(), np.abs(got[:, 1] - np.cos(ang)).max())
+    lib = max(np.abs(got[:, 2] - np.sin(ang)).max(), np.abs(got[:, 3] - np.cos(ang)).max())
+    print("sin / cos of 2 pi u: max |error| hardware %.3e, libm path %.3e (the libm path rounds 2 pi u to fp32 first)" % (hw, lib))
+    assert hw <= 1e-6 and lib <= 1e-6
+    # the helpers at the fast level (ops 32..38) against the reference's own vectors
+    cases = [
+        (32, cat(G["math_onb_n"], G["math_onb_p"]), 3, G["math_onb_out"], "OrthonormalBasis", 4e-7),
+        (33, cat(G["math_sdiv_a"], G["math_sdiv_b"]), 3, G["math_sdiv3_out"], "safeDivide x 3 (roulette)", 4e-7),
+        # sin(acos(sqrt(e1))) as sqrt(1 - e1): the reference's own form loses digits where sqrt(e1) rounds next to 1 (theta ~ 0: acos
+        # of a value 1 ulp off), so its vectors carry up to 1e-4 of their own rounding there; held against them loosely here and
+        # against the exact values below
+        (34, cat(G["math_u1"], G["math_u2"]), 3, G["math_cosine_out"], "cosine_sample_hemisphere", 3e-4),
+        (35, cat(G["math_u1"], G["math_u2"]), 3, G["math_uniform_out"], "uniform_sample_hemisphere", 1e-6),
+        # sinTheta = sqrt(1 - cosTheta^2) next to cosTheta = 1 (small u2) multiplies the quotient's 2 ulp by cos / sin: the form's own conditioning
+        (36, cat(G["math_u1"], G["math_u2"], G["math_ggx_rough"], G["math_onb_n"]), 3, G["math_ggx_out"], "sampleGGX", 5e-5),
+        (37, cat(G["math_fc_cos"], G["math_fc_eta"], G["math_fc_k"]), 3, G["math_fc_out"], "fresnelSchlickConductor", 4e-7),
+        (38, cat(G["math_fd_cos"], G["math_fd_etai"], G["math_fd_etat"]), 1, G["math_fd_out"].reshape(-1, 1), "FrDielectric", 3e-5),      # cosThetaT = sqrt(1 - sinThetaT^2) next to total internal reflection: the same conditioning
+    ]
+    for op, rec, ow, want, name, tol in cases:
+        got = run(ctx, op, rec, n, np.zeros((n, ow), np.float32))
+        want = np.asarray(want, np.float32).reshape(n, ow)
+        ok = np.isfinite(want).all(axis=1)
+        # relative to max(1, |value|): unit-vector components and Fresnel terms are O(1); safeDivide's quotients can be large
+        err = np.abs(got[ok].astype(np.float64) - want[ok].astype(np.float64)) / np.maximum(1.0, np.abs(want[ok].astype(np.float64)))
+        print("%s at the fast level: max error %.3e (bound %.1e), %.1f%% of components bit-identical to the reference's vectors" %
+              (name, err.max(), tol, 100 * (got[ok] == want[ok]).mean()))
+        assert err.max() <= tol, (name, err.max())
+        assert np.isfinite(got[ok]).all()
+        if op == 34:
+            e1, e2 = np.asarray(G["math_u1"], np.float64).reshape(-1), np.asarray(G["math_u2"], np.float64).reshape(-1)
+            exact = np.stack([np.sqrt(1 - e1) * np.cos(2 * np.pi * e2), np.sqrt(1 - e1) * np.sin(2 * np.pi * e2), np.sqrt(e1)], axis=1)
+            ex_err = np.abs(got.astype(np.float64) - exact).max()
+            ref_err = np.abs(np.asarray(G["math_cosine_out"], np.float64).reshape(n, 3) - exact).max()
+            print("cosine_sample_hemisphere against the exact values: fast level %.3e, the reference's vectors %.3e" % (ex_err, ref_err))
+            assert ex_err <= 5e-7
+
+
 def _exact_slab(o, d, lo, hi, tmin, tmax):
     """Ray / box in float64 on the very fp32 values the device gets: True where the ray meets the box within [tmin, tmax]."""
     o, d, lo, hi = (x.astype(np.float64) for x in (o, d, lo, hi))

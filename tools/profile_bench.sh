@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="${@:---no-cpu-baseline}"
+ARGS="${@:---no-cpu-baseline} --no-ieee-leg"      # one render-kernel instantiation in the trace
 echo "== kernel trace" 
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $REPO/bench.py $ARGS > $OUT/trace.log 2>&1 || { echo trace failed; tail -5 $OUT/trace.log; exit 1; }
 i=0

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--build-mode", type=int, default=None, help="0 Karras LBVH, 1 PLOC (library default)")
     ap.add_argument("--fuse", type=int, default=1, help="sub-frames per kernel launch (pt_launch_frames)")
     ap.add_argument("--pixel-classes", type=int, default=1, help="0: every path start tests its camera ray against the scene box (pt_debug_pixel_classes)")
+    ap.add_argument("--math", type=int, default=1, help="pt_set_math_mode: 1 fast (the library default), 0 ieee; experiment rows without a fast twin run ieee either way")
     ap.add_argument("--queue-order", type=int, default=1, help="1: tile-strip rows interleaved over the queue shards (pt_debug_queue_order)")
     a = ap.parse_args()
     L = _native.hip()
@@ -44,6 +45,7 @@ def main():
     state.params.accumulationBuffer, state.params.handle = keep_a, keep_h
     rank, world = [int(x) for x in a.partition.split(",")]
     assert L.pt_set_partition(state.context, rank, world) == 0
+    assert L.pt_set_math_mode(state.context, a.math) == 0
     assert L.pt_debug_queue_order(state.context, a.queue_order) == 0
     assert L.pt_debug_pixel_classes(state.context, a.pixel_classes) == 0
     info = pt.getBvhInfo(state)
@@ -89,7 +91,7 @@ def main():
         if s.trav_wave_steps:
             print("      wave-steps %.4g  shade rounds %.4g  rays %.4g  paths %.4g  pixels %d" % (s.trav_wave_steps, s.shade_wave_rounds, rays, s.paths, s.pixels))
         print("%-4d %-4d %-3d %-6d %9.3f %9.3f %9.1f %8.3f %8.3f %8.2f  %-5s  %s" %
-              (v, bpc, ch, s.grid_blocks, ms[0], ms[len(ms) // 2], rays / ms[0] / 1e3, te, se, spr, e["hash"] == ref_hash, L.pt_variant_name(v).decode()))
+              (v, bpc, ch, s.grid_blocks, ms[0], ms[len(ms) // 2], rays / ms[0] / 1e3, te, se, spr, e["hash"] == ref_hash, ("[fast] " if s.math_mode else "[ieee] ") + L.pt_variant_name(v).decode()))
     pt.CleanAllTheThings(state)
 
 
