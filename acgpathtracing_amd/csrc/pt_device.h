@@ -124,14 +124,35 @@ __device__ __forceinline__ f3 normalize(const f3& v) { float invLen = 1.0f / sqr
 //   0  IEEE: correctly rounded division and square root, OCML sincosf / acosf — the level the CPU oracle is written at;
 //   1  level 0 with the cosine sampler's trigonometry on v_sin_f32 / v_cos_f32 and sqrt(1 - z1) for sin(acos(sqrt(z1)));
 //   2  what nvcc --use_fast_math makes of the reference's own build (CMakeLists.txt:267: -prec-div=false -prec-sqrt=false,
-//      sinf -> __sinf, cosf -> __cosf): a / b = a * v_rcp_f32(b), v_sqrt_f32, v_rsq_f32, v_sin_f32 / v_cos_f32 (1 ulp each).
+//      sinf -> __sinf, cosf -> __cosf, and nvcc's default -fmad=true): a / b = a * v_rcp_f32(b), v_sqrt_f32, v_rsq_f32,
+//      v_sin_f32 / v_cos_f32 (1 ulp each), and multiply-adds fused where they are spelled out below (m_dot, m_cross, m_madd:
+//      nvcc contracts where it sees fit; here the placement is explicit, so every kernel variant computes the same bits).
 // Traversal and the triangle test are the same at every level (hits stay bit-exact); only shading values move in their last bits.
 template <int FM> __device__ __forceinline__ float m_div(float a, float b) { return FM >= 2 ? a * __builtin_amdgcn_rcpf(b) : a / b; }
 template <int FM> __device__ __forceinline__ float m_sqrt(float x) { return FM >= 2 ? __builtin_amdgcn_sqrtf(x) : sqrtf(x); }
-template <int FM> __device__ __forceinline__ float m_length(const f3& v) { return m_sqrt<FM>(dot(v, v)); }
+template <int FM> __device__ __forceinline__ float m_dot(const f3& a, const f3& b)
+{ return FM >= 2 ? __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)) : a.x * b.x + a.y * b.y + a.z * b.z; }
+template <int FM> __device__ __forceinline__ f3 m_cross(const f3& a, const f3& b)
+{
+    if (FM >= 2) return mk(__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)), __builtin_fmaf(a.x, b.y, -(a.y * b.x)));
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// a * s + b
+template <int FM> __device__ __forceinline__ f3 m_madd(const f3& a, float s, const f3& b)
+{
+    if (FM >= 2) return mk(__builtin_fmaf(a.x, s, b.x), __builtin_fmaf(a.y, s, b.y), __builtin_fmaf(a.z, s, b.z));
+    return mk(a.x * s + b.x, a.y * s + b.y, a.z * s + b.z);
+}
+// a * b + c, component by component
+template <int FM> __device__ __forceinline__ f3 m_madd(const f3& a, const f3& b, const f3& c)
+{
+    if (FM >= 2) return mk(__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y), __builtin_fmaf(a.z, b.z, c.z));
+    return mk(a.x * b.x + c.x, a.y * b.y + c.y, a.z * b.z + c.z);
+}
+template <int FM> __device__ __forceinline__ float m_length(const f3& v) { return m_sqrt<FM>(m_dot<FM>(v, v)); }
 template <int FM> __device__ __forceinline__ f3 m_normalize(const f3& v)
 {
-    if (FM >= 2) return v * __builtin_amdgcn_rsqf(dot(v, v));
+    if (FM >= 2) return v * __builtin_amdgcn_rsqf(m_dot<FM>(v, v));
     const float invLen = 1.0f / sqrtf(dot(v, v));
     return v * invLen;
 }

@@ -31,8 +31,8 @@ __device__ __forceinline__ void onb_transform(const f3& n, f3& p)
     if (fabsf(n.x) > fabsf(n.z)) bn = mk(-n.y, n.x, 0.0f);
     else                         bn = mk(0.0f, -n.z, n.y);
     bn = m_normalize<FM>(bn);
-    const f3 tg = cross(bn, n);
-    p = p.x * tg + p.y * bn + p.z * n;
+    const f3 tg = m_cross<FM>(bn, n);
+    p = FM >= 2 ? m_madd<FM>(n, p.z, m_madd<FM>(bn, p.y, p.x * tg)) : p.x * tg + p.y * bn + p.z * n;
 }
 // cosine_sample_hemisphere :341-353.  sincosf shares one argument reduction between the sine and the cosine of an
 // angle; OCML's sinf / cosf are that same reduction + kernel with one output selected, so the values are the ones
@@ -122,6 +122,16 @@ __device__ __forceinline__ bool refract_dir(f3& r, const f3& i, const f3& n, flo
 }
 template <int FM = 0>
 __device__ __forceinline__ float safe_div(float a, float b) { return b == 0.0f ? 0.0f : m_div<FM>(a, b); }
+// What a finished segment adds to the pixel (raygen :761-762: result += radiance * attenuation) and the roulette's survival
+// probability (:766: the throughput's luminance); multiply-adds fused at the fast level
+template <int FM = 0>
+__device__ __forceinline__ void add_segment(f3& result, const f3& radiance, const f3& att)
+{
+    if (FM >= 2) result = m_madd<FM>(radiance, att, result);
+    else result += radiance * att;
+}
+template <int FM = 0>
+__device__ __forceinline__ float roulette_p(const f3& att) { return m_dot<FM>(att, mk(0.30f, 0.59f, 0.11f)); }
 // Throughput of a path that survives the roulette (:771-777: each component safeDivide'd by the survival probability); at the
 // fast arithmetic level the three quotients share one reciprocal
 template <int FM = 0>
@@ -198,8 +208,8 @@ __device__ __forceinline__ bool shade_hit(const DeviceScene& sc, Late late, cons
     const float IOR = mp->ior;
     const int bsdf = mp->bsdfType;
     const f3 N0 = mk(sr.x, sr.y, sr.z);
-    const f3 N = faceforward(N0, -dir, N0);
-    P = org + t_hit * dir;                                                       // :894
+    const f3 N = FM >= 2 ? N0 * copysignf(1.0f, -m_dot<FM>(dir, N0)) : faceforward(N0, -dir, N0);
+    P = FM >= 2 ? m_madd<FM>(dir, t_hit, org) : org + t_hit * dir;              // :894
     emission = depth == 0 ? Ke : mk(0.0f);                                       // :898-901
     uint32_t s = pseed;
     pd.nxt_org = org; pd.nxt_dir = dir;
@@ -248,11 +258,12 @@ __device__ __forceinline__ bool shade_hit(const DeviceScene& sc, Late late, cons
     bool want_shadow = false;
     const auto& La = late();
     if (La.useDL && bsdf != PT_BSDF_REFRACTION) {                                // :1003-1026
-        const f3 light_pos = mk(La.light.corner) + mk(La.light.v1) * z1 + mk(La.light.v2) * z2;
+        const f3 light_pos = FM >= 2 ? m_madd<FM>(mk(La.light.v2), z2, m_madd<FM>(mk(La.light.v1), z1, mk(La.light.corner)))
+                                     : mk(La.light.corner) + mk(La.light.v1) * z1 + mk(La.light.v2) * z2;
         Ldist = m_length<FM>(light_pos - P);
         L = m_normalize<FM>(light_pos - P);
-        const float nDl = dot(N, L);
-        const float LnDl = -dot(mk(La.light.normal), L);
+        const float nDl = m_dot<FM>(N, L);
+        const float LnDl = -m_dot<FM>(mk(La.light.normal), L);
         want_shadow = nDl > 0.0f && LnDl > 0.0f;
         pd.weight = m_div<FM>(nDl * LnDl * La.light_area, kPIf * Ldist * Ldist);         // :1021-1022 (|v1 x v2| from the host), used only if unoccluded
     }

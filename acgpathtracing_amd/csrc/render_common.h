@@ -316,6 +316,10 @@ __device__ __forceinline__ void finish_runs(const RenderArgs& A, QueueState& q, 
 template <int FM = 0>
 __device__ __forceinline__ f3 camera_dir(float px, float py, float jx, float jy, float fw, float fh, const f3& U, const f3& V, const f3& W)
 {
+    if (FM >= 2) {
+        const float dx = __builtin_fmaf(2.0f, m_div<FM>(px + jx, fw), -1.0f), dy = __builtin_fmaf(2.0f, m_div<FM>(py + jy, fh), -1.0f);
+        return m_madd<FM>(V, dy, m_madd<FM>(U, dx, W));
+    }
     const float dx = 2.0f * m_div<FM>(px + jx, fw) - 1.0f;
     const float dy = 2.0f * m_div<FM>(py + jy, fh) - 1.0f;
     return dx * U + dy * V + W;

@@ -122,14 +122,14 @@ k_render(const RenderArgsBox B)
             HitRec sh;
             const bool occluded = traverse<true>(sc, st, want_shadow, P, L, 0.01f, Ldist - 0.01f, sh);
             n_shadow += (unsigned long long)popc(shadow_mask);
-            if (want_shadow && !occluded) pd.radiance += mk(A.light.emission) * pd.weight;
+            if (want_shadow && !occluded) pd.radiance = m_madd<FM>(mk(A.light.emission), pd.weight, pd.radiance);
         }
 
         bool end = false, finished = false;
         if (lp.alive) {                                               // raygen :760-778
             lp.result += emission;
-            lp.result += pd.radiance * att;
-            const float p = dot(att, mk(0.30f, 0.59f, 0.11f));
+            add_segment<FM>(lp.result, pd.radiance, att);
+            const float p = roulette_p<FM>(att);
             const bool rr = rnd(pseed) > p;
             end = pd.done || rr || (uint32_t)depth >= A.maxDepth;
             if (!end) {
@@ -341,7 +341,7 @@ k_render_pw(const RenderArgsBox B)
                     pd.nxt_dir = keep_dir;
                     pd.nxt_org = keep_metal ? ro + keep_dir * 1e-4f : ro;             // ro is the shadow ray's origin P
                     pd.radiance = keep_done ? keep_dir : mk(0.0f);
-                    if (!shadow_hit) pd.radiance += mk(late().light.emission) * pd.weight;
+                    if (!shadow_hit) pd.radiance = m_madd<FM>(mk(late().light.emission), pd.weight, pd.radiance);
                 }
                 shadow_ray = false;
                 segment_done = true;
@@ -376,8 +376,8 @@ k_render_pw(const RenderArgsBox B)
         bool end = false, finished = false;
         if (segment_done) {                                           // raygen :761-778
             if (LIGHTS) lp.result += pd.radiance;                     // light mode 1: already times the throughput
-            else lp.result += pd.radiance * att;
-            float p = dot(att, mk(0.30f, 0.59f, 0.11f));
+            else add_segment<FM>(lp.result, pd.radiance, att);
+            float p = roulette_p<FM>(att);
             if (LIGHTS) p = fminf(p, 1.0f);                           // the 2 cos weight can lift the throughput above 1; a survival probability is <= 1
             const bool rr = rnd(pseed) > p;
             end = pd.done || rr || (uint32_t)depth >= A.maxDepth;

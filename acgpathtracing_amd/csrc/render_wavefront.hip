@@ -587,7 +587,7 @@ k_render_wf(const RenderArgsBox B)
                     pd.radiance = pd.done ? nd : mk(0.0f);
                     pd.nxt_dir = nd;
                     pd.nxt_org = (r[F_TAGF] & kTagMetal) ? ro + nd * 1e-4f : ro;      // ro is the shadow ray's origin P (:926, :948)
-                    if (hit < 0) pd.radiance += mk(late().light.emission) * pd.weight;
+                    if (hit < 0) pd.radiance = m_madd<FM>(mk(late().light.emission), pd.weight, pd.radiance);
                     segment_done = true;
                 } else {                                                  // radiance ray back
                     bool want_shadow = false;
@@ -615,8 +615,8 @@ k_render_wf(const RenderArgsBox B)
             n_shadow += (unsigned long long)popc(vote(started_shadow));
             bool end = false, finished = false, new_path = false, start_radiance = false;
             if (segment_done) {                                           // raygen :761-778
-                result += pd.radiance * att;
-                const float p = dot(att, mk(0.30f, 0.59f, 0.11f));
+                add_segment<FM>(result, pd.radiance, att);
+                const float p = roulette_p<FM>(att);
                 const bool rr = rnd(pseed) > p;
                 end = pd.done || rr || (uint32_t)depth >= late().maxDepth;
                 if (!end) {
