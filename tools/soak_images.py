@@ -12,7 +12,7 @@ import numpy as np  # noqa: E402
 import acgpathtracing_amd as pt  # noqa: E402
 from acgpathtracing_amd import _native  # noqa: E402
 import oracle_lib  # noqa: E402
-from scene_utils import copy_params, image_mse, make_params  # noqa: E402
+from scene_utils import copy_params, image_mse, image_mse_trimmed, make_params  # noqa: E402
 
 
 def main():
@@ -20,14 +20,17 @@ def main():
     ap.add_argument("--cases", type=int, default=30)
     ap.add_argument("--scene", default="cornell_box.obj")
     ap.add_argument("--variant", type=int, default=-1, help="kernel variant (pt_set_tuning; -1 = the library's choice)")
+    ap.add_argument("--math", default="fast", choices=["fast", "ieee"], help="pt_set_math_mode: fast (the library default) or ieee (the oracle's arithmetic level)")
     a = ap.parse_args()
     L = _native.hip()
     orc = oracle_lib.load()
     state, obj = pt.setup(os.path.join(pt.SCENES, a.scene), width=96, height=64)
     sc = orc.scene(obj.getVerticesFloat(), obj.getIndexBuffer(), obj.getMaterialIndices(), obj.getMaterials())
     assert L.pt_set_tuning(state.context, 0, a.variant) == 0
+    pt.setMathMode(state, a.math)
     rng = np.random.default_rng(2024)
     worst = 0.0
+    hist = {"is_on": [], "is_off": [], "is_off_trimmed": []}
     for k in range(a.cases):
         w, h = int(rng.choice([64, 96, 130])), int(rng.choice([48, 64, 75]))
         spp = int(rng.choice([4, 8, 16])); depth = int(rng.integers(1, 17))
@@ -63,6 +66,9 @@ def main():
             differ = ~np.all(acc.view(np.uint32) == ref.view(np.uint32), axis=-1)
             same = 1.0 - float(differ.mean())
             worst = max(worst, mse)
+            hist["is_on" if isamp else "is_off"].append(mse)
+            if not isamp:
+                hist["is_off_trimmed"].append(image_mse_trimmed(acc, ref, 1e-3))
             flag = "" if mse < 1e-3 and np.isfinite(acc).all() else "   <-- FAIL"
             print("case %2d %3dx%-3d spp %2d depth %2d DL %d IS %d %s frames %d runs %2d: MSE %.2e, %.1f %% pixels bit-identical%s"
                   % (k, w, h, spp, depth, dl, isamp, "inside " if inside else "outside", frames, st.sample_chunks, mse, 100 * same, flag))
@@ -71,7 +77,11 @@ def main():
                 ys, xs = np.unravel_index(np.argsort(d2, axis=None)[::-1][:3], d2.shape)
                 print("        %d pixels differ; largest: %s" % (int(differ.sum()), "; ".join("(%d,%d) gpu %s cpu %s" % (x, y, acc[y, x, :3], ref[y, x, :3]) for y, x in zip(ys, xs) if d2[y, x] > 0)))
             sys.stdout.flush()
-    print("worst MSE %.3e" % worst)
+    print("worst MSE %.3e (math mode %s)" % (worst, a.math))
+    for k, v in hist.items():
+        if v:
+            v = np.sort(np.asarray(v))
+            print("  %-15s n %3d: median %.2e, 90 %% %.2e, max %.2e, below 1e-6: %d" % (k, v.size, v[v.size // 2], v[int(0.9 * (v.size - 1))], v[-1], int((v < 1e-6).sum())))
     sc.close()
     pt.CleanAllTheThings(state)
     return 0 if worst < 1e-3 else 1
