@@ -38,7 +38,7 @@ struct pt_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // bracket the render kernel alone (k_finalize sits outside)
     ptd::LbvhResult bvh;
-    pt_material* d_mats = nullptr;
+    ptd::DevMaterial* d_mats = nullptr;       // pt_material repacked into two aligned 16-byte halves (pt_device.h)
     uint32_t n_mats = 0;
     float4* d_lights = nullptr;               // emissive triangles of the scene (light mode 1), 5 float4 each
     uint32_t n_lights = 0;
@@ -354,6 +354,7 @@ static int set_scene_one(pt_ctx* c, const float* verts_xyzw, size_t n_verts, con
         if (mat_ids[i] >= n_mats) return fail(c, "pt_set_scene: material index out of range (a face without a known usemtl has id 0xFFFFFFFF)");
     for (size_t i = 0; i < n_mats; i++)
         if (mats[i].bsdfType < 0 || mats[i].bsdfType > 2) return fail(c, "pt_set_scene: unknown bsdfType");
+    if (n_mats > (size_t)ptd::kShadeMatMask + 1u) return fail(c, "pt_set_scene: more than 2^24 materials");
     CK(c, hipSetDevice(c->device));
     CK(c, hipStreamSynchronize(c->stream));
     Range range("acgpt: scene upload + BVH build");
@@ -361,8 +362,16 @@ static int set_scene_one(pt_ctx* c, const float* verts_xyzw, size_t n_verts, con
     std::string err;
     if (!ptd::build_lbvh(verts_xyzw, n_verts, idx, n_tris, mat_ids, c->build_mode, c->stream, c->bvh, err)) return fail(c, "pt_set_scene: " + err);
     if (n_mats) {
-        CK(c, hipMalloc((void**)&c->d_mats, n_mats * sizeof(pt_material)));
-        CK(c, hipMemcpy(c->d_mats, mats, n_mats * sizeof(pt_material), hipMemcpyHostToDevice));
+        std::vector<ptd::DevMaterial> dm(n_mats);
+        for (size_t i = 0; i < n_mats; i++) {
+            const pt_material& m = mats[i];
+            uint32_t b = (uint32_t)m.bsdfType; float bf; memcpy(&bf, &b, 4);
+            dm[i].kd_ior = make_float4(m.diffuse.x, m.diffuse.y, m.diffuse.z, m.ior);
+            dm[i].ke_bsdf = make_float4(m.emission.x, m.emission.y, m.emission.z, bf);
+        }
+        CK(c, hipMalloc((void**)&c->d_mats, n_mats * sizeof(ptd::DevMaterial)));
+        CK(c, hipMemcpy(c->d_mats, dm.data(), n_mats * sizeof(ptd::DevMaterial), hipMemcpyHostToDevice));
+        if (!ptd::tag_shade_records(c->bvh, c->d_mats, c->stream, err)) return fail(c, "pt_set_scene: " + err);
     }
     c->n_mats = (uint32_t)n_mats;
     {   // light mode 1: every triangle with an emissive material, in triangle order; same fp32 operations as the oracle's

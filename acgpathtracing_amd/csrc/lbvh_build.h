@@ -40,6 +40,11 @@ bool build_lbvh(const float* h_verts_xyzw, size_t n_verts, const uint32_t* h_idx
 
 void free_lbvh(LbvhResult& r);
 
+// Writes each material's bsdfType and whether it emits into the upper byte of the shade records' material word (pt_device.h
+// kShadeBsdfShift, kShadeHasKe), once the repacked materials are on the device: what lets closest-hit shading fetch
+// {diffuse, ior} alone for a diffuse, non-emissive hit.  Synchronous on return.
+bool tag_shade_records(LbvhResult& r, const DevMaterial* d_mats, hipStream_t stream, std::string& err);
+
 // The first kTopNodesMax inner nodes breadth first (LbvhResult::top_nodes), on first use (experiment variants only).
 bool build_top_nodes(LbvhResult& r, hipStream_t stream, std::string& err);
 

@@ -744,6 +744,26 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
     return true;
 }
 
+__global__ void k_tag_shade(float4* __restrict__ shade, uint32_t n, const DevMaterial* __restrict__ mats)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t id = __float_as_uint(shade[i].w) & kShadeMatMask;
+    const float4 m1 = mats[id].ke_bsdf;
+    const bool has_ke = !(m1.x == 0.0f && m1.y == 0.0f && m1.z == 0.0f);          // a NaN component counts: the fetch it stands for would return it
+    shade[i].w = __uint_as_float(id | ((__float_as_uint(m1.w) & 3u) << kShadeBsdfShift) | (has_ke ? kShadeHasKe : 0u));
+}
+
+bool tag_shade_records(LbvhResult& r, const DevMaterial* d_mats, hipStream_t stream, std::string& err)
+{
+    if (!r.shade || r.n_tris == 0 || !d_mats) return true;
+    k_tag_shade<<<(r.n_tris + 255u) / 256u, 256, 0, stream>>>(r.shade, r.n_tris, d_mats);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) { err = std::string("shade records: ") + hipGetErrorString(e); return false; }
+    return true;
+}
+
 // The breadth-first copy of the tree's top (k_top_nodes): built on first use by a kernel variant that stages it in LDS — an
 // experiment; not part of the default scene set-up.
 bool build_top_nodes(LbvhResult& r, hipStream_t stream, std::string& err)

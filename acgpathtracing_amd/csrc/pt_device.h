@@ -10,8 +10,12 @@
 //            needs no second fetch through the index buffer.
 //   shade  : float4[n_tris], same order: the triangle's geometric normal — normalize(cross(e1, e2)), the very operations of
 //            pathTracerPrograms.cu:890, done once by the builder — and its material id: one 16-byte fetch per shaded hit
-//            instead of the record's three, and no normalisation (a sqrt and a division) in the shade phase.
-//   mats   : pt_material[n_mats] (40 B, HitGroupData's payload, pathTracer.h:118-127).
+//            instead of the record's three, and no normalisation (a sqrt and a division) in the shade phase.  The id's upper
+//            byte carries the material's bsdfType and whether its emission is non-zero (tag_shade_records), so a diffuse,
+//            non-emissive hit — nearly all of them — needs ONE further fetch: {diffuse, ior}.
+//   mats   : DevMaterial[n_mats]: pt_material (40 B, HitGroupData's payload, pathTracer.h:118-127) repacked at upload into two
+//            aligned 16-byte halves, {diffuse, ior} and {emission, bsdfType}; roughness and metallic, which the reference's
+//            shading ignores (:879-880), are not carried.
 // Compile with -ffp-contract=off: the only fused multiply-adds are the explicit ones in
 // tri_test(), which must match oracle/oracle_pt.cpp bit for bit.
 #pragma once
@@ -70,6 +74,11 @@ struct QGrid {
     float cx, cy, cz;
 };
 
+// pt_material as the kernels read it (capi.hip repacks at upload): two aligned 16-byte loads instead of 40 unaligned bytes
+struct DevMaterial { float4 kd_ior; float4 ke_bsdf; };      // diffuse.xyz + ior | emission.xyz + bsdfType (as bits)
+// shade record .w: material id in the low 24 bits, bsdfType above, and a flag: the material's emission has a non-zero component
+constexpr uint32_t kShadeMatMask = 0x00FFFFFFu, kShadeBsdfShift = 24u, kShadeHasKe = 1u << 26;
+
 struct DeviceScene {
     const BvhNode*     nodes;
     const QNode*       qnodes;
@@ -82,7 +91,7 @@ struct DeviceScene {
     const TriRecord*   tris;
     const float4*      shade;     // per leaf slot: geometric normal normalize(cross(e1, e2)) (:890) and material id — what closest-hit shading reads
     const uint4*       wrecs;     // four-wide tree: 48-byte records, wide nodes and triangles in one array (wide_bvh.hip)
-    const pt_material* mats;
+    const DevMaterial* mats;
     uint32_t n_tris;
     uint32_t n_mats;
     // light mode 1 (pt_set_light_mode): the scene's emissive triangles, 5 float4 each:

@@ -203,10 +203,20 @@ __device__ __forceinline__ bool shade_hit(const DeviceScene& sc, Late late, cons
     } else {
         sr = sc.shade[slot];                                                     // computed once by the builder (k_gather_leaves)
     }
-    const pt_material* mp = sc.mats + __float_as_uint(sr.w);
-    const f3 Kd = mk(mp->diffuse), Ke = mk(mp->emission);
-    const float IOR = mp->ior;
-    const int bsdf = mp->bsdfType;
+    // the builder's record names the material, its bsdfType and whether it emits: {diffuse, ior} is the one fetch every hit
+    // needs, the emission is fetched for emitters only (zero otherwise: what the fetch would return)
+    const uint32_t mw = __float_as_uint(sr.w);
+    const DevMaterial* mp = sc.mats + (mw & kShadeMatMask);
+    const float4 m0 = mp->kd_ior;
+    const f3 Kd = mk(m0.x, m0.y, m0.z);
+    const float IOR = m0.w;
+    f3 Ke = mk(0.0f);
+    int bsdf = (int)((mw >> kShadeBsdfShift) & 3u);
+    if (FROM_RECORD || (mw & kShadeHasKe) != 0u) {       // FROM_RECORD: a plain material id from the triangle record
+        const float4 m1 = mp->ke_bsdf;
+        Ke = mk(m1.x, m1.y, m1.z);
+        if (FROM_RECORD) bsdf = (int)__float_as_uint(m1.w);
+    }
     const f3 N0 = mk(sr.x, sr.y, sr.z);
     const f3 N = FM >= 2 ? N0 * copysignf(1.0f, -m_dot<FM>(dir, N0)) : faceforward(N0, -dir, N0);
     P = FM >= 2 ? m_madd<FM>(dir, t_hit, org) : org + t_hit * dir;              // :894
@@ -284,9 +294,14 @@ __device__ __forceinline__ bool shade_hit_lights(const DeviceScene& sc, Late lat
                                                  Pending& pd, f3& P, f3& L, float& Ldist)
 {
     const float4 sr = sc.shade[slot];
-    const pt_material* mp = sc.mats + __float_as_uint(sr.w);
-    const f3 Kd = mk(mp->diffuse), Ke = mk(mp->emission);
-    const int bsdf = mp->bsdfType;
+    const uint32_t mw = __float_as_uint(sr.w);
+    const DevMaterial* mp = sc.mats + (mw & kShadeMatMask);
+    const float4 m0 = mp->kd_ior;
+    const f3 Kd = mk(m0.x, m0.y, m0.z);
+    const float ior = m0.w;
+    f3 Ke = mk(0.0f);
+    if ((mw & kShadeHasKe) != 0u) { const float4 m1 = mp->ke_bsdf; Ke = mk(m1.x, m1.y, m1.z); }
+    const int bsdf = (int)((mw >> kShadeBsdfShift) & 3u);
     const f3 N0 = mk(sr.x, sr.y, sr.z);
     const f3 N = faceforward(N0, -dir, N0);
     P = org + t_hit * dir;
@@ -337,12 +352,12 @@ __device__ __forceinline__ bool shade_hit_lights(const DeviceScene& sc, Late lat
     } else if (bsdf == PT_BSDF_REFRACTION) {
         const f3 inc = m_normalize<FM>(dir);
         const float cos_theta = dot(m_normalize<FM>(-dir), N0);
-        const float F = fr_dielectric<FM>(cos_theta, 1.0f, mp->ior);
+        const float F = fr_dielectric<FM>(cos_theta, 1.0f, ior);
         if (rnd(s) < F) {
             pd.nxt_dir = reflect(inc, N0);
         } else {
             f3 rd;
-            pd.nxt_dir = refract_dir<FM>(rd, inc, N0, mp->ior) ? rd : reflect(inc, N0);
+            pd.nxt_dir = refract_dir<FM>(rd, inc, N0, ior) ? rd : reflect(inc, N0);
         }
         pd.nxt_org = P + pd.nxt_dir * 1e-3f;
         att = att_in * Kd;
