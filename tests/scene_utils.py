@@ -106,10 +106,12 @@ def adversarial_rays(verts, idx, seed, n_per_kind=2000):
 
 def image_mse_trimmed(a, b, drop):
     """image_mse over all but the `drop` fraction of pixels that differ most.  For the comparison of two arithmetic levels in
-    uniform-hemisphere mode: there one bounce in ~10^5 leaves its wall at a slope below 1e-5 and skims along it; whether it
-    meets that wall's plane again a few hundred units on is decided by the last bits of its direction (and of the hit point it
-    starts from), so two correct implementations that differ in those bits trace different paths for that sample — a whole
-    path's radiance in one pixel, in either direction.  The trimmed value says that everything else agrees."""
+    uniform-hemisphere mode: there three bounces in a thousand leave their surface at a slope below 3e-3, and the reference
+    starts them AT the hit point with an absolute tmin of 0.01; a hit point that rounded to the far side of its surface sends
+    such a ray through the surface's own plane again beyond tmin.  Which rays do is decided by the last bits of the hit point
+    and of the direction, so two correct implementations that differ in those bits trace different paths for that sample — a
+    whole path's radiance in one pixel, in either direction.  The trimmed value says that everything
+    else agrees."""
     x = np.clip(a[..., :3].astype(np.float64), 0.0, 1.0)
     y = np.clip(b[..., :3].astype(np.float64), 0.0, 1.0)
     per_pixel = np.mean((x - y) ** 2, axis=-1).reshape(-1)

@@ -32,5 +32,11 @@ for isamp in (False, True):
             a, sa = render(p, "ieee"); b, sb = render(p, "fast")
             diff = np.any(a.view(np.uint32) != b.view(np.uint32), axis=-1)
             big = np.abs(a[..., :3] - b[..., :3]).max(axis=-1) > 1e-3 * np.maximum(1e-3, np.abs(a[..., :3]).max(axis=-1))
+            if not isamp and not dl and depth in (1, 8):      # who carries the difference: the pixels that differ most, both values
+                d2 = ((a[..., :3].astype(np.float64) - b[..., :3]) ** 2).sum(axis=-1)
+                ys, xs = np.unravel_index(np.argsort(d2, axis=None)[::-1][:6], d2.shape)
+                print("    largest differences at depth %d: %s" % (depth, "; ".join("(%d,%d) ieee %s fast %s" % (x, y, np.round(a[y, x, :3], 3), np.round(b[y, x, :3], 3)) for y, x in zip(ys, xs))))
+                print("    pixels that see the emitter directly (red > 10): %d of %d; of the %d pixels differing by > 1e-3, on the emitter: %d"
+                      % (int((a[..., 0] > 10).sum()), a.shape[0] * a.shape[1], int(big.sum()), int((big & (a[..., 0] > 10)).sum())))
             print("IS %d DL %d depth %d: MSE %.3e, pixels with other bits %.4f, pixels differing by > 1e-3 rel: %d; rays %d vs %d, shadow %d vs %d"
                   % (isamp, dl, depth, image_mse(a, b), diff.mean(), int(big.sum()), sa.radiance_rays, sb.radiance_rays, sa.shadow_rays, sb.shadow_rays))
