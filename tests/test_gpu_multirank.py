@@ -103,6 +103,10 @@ def test_group_context_behind_the_c_abi(built, tmp_path):
         grp = _app(tmp_path, "grp%d" % n, ["--gpus", str(n)], reh)
         assert "Devices: %d" % n in grp[2]
         assert grp[:2] == one[:2], "--gpus %d differs from one device" % n
+    # the math mode fans out to every rank: the IEEE level on a group == on one device (and differs from the default's bits)
+    one_i = _app(tmp_path, "one_ieee", ["--math", "ieee"])
+    grp_i = _app(tmp_path, "grp_ieee", ["--gpus", "2", "--math", "ieee"], reh)
+    assert grp_i[:2] == one_i[:2] and one_i[1] != one[1]
     # without the rehearsal switch a device listed twice is refused
     import ctypes as C
     from acgpathtracing_amd import _native
