@@ -85,6 +85,17 @@ def diffuse(gpu_state_factory, oracle):
     return state, obj, sc
 
 
+@pytest.fixture(params=["ieee", "fast"])
+def both_modes(request, full, diffuse):
+    """For the tests that compare the GPU with itself (scheduling, partition, batches: bit-identical whatever the arithmetic):
+    run them at the oracle's level and in the library's default math mode."""
+    for st in (full[0], diffuse[0]):
+        pt.setMathMode(st, request.param)
+    yield request.param
+    for st in (full[0], diffuse[0]):
+        pt.setMathMode(st, "ieee")
+
+
 def test_library_is_the_hip_one():
     L = _native.hip()
     assert L.pt_abi_version() == 3
@@ -249,7 +260,7 @@ def test_progressive_accumulation(full):
 
 
 @pytest.mark.parametrize("chunks", [0, 1, 4])
-def test_frame_batches_equal_separate_launches(full, chunks):
+def test_frame_batches_equal_separate_launches(full, chunks, both_modes):
     """pt_launch_frames: n sub-frames in one kernel launch leave accumulation and framebuffer bit-identical to n
     pt_launch calls — batches of 2, 3 (not a power of two: padded work items), 5 and 8, and a batch that
     continues an accumulation (first frame > 0 folds into what is already there)."""
@@ -330,7 +341,7 @@ def test_every_kernel_variant_gives_the_same_bits(full, mode):
     assert tried >= 4
 
 
-def test_queue_order_and_pixel_classes_change_no_bit(diffuse):
+def test_queue_order_and_pixel_classes_change_no_bit(diffuse, both_modes):
     """How the work queue is dealt over its eight shards (contiguous bands, rows or tiles round robin, or one queue) and whether pixels are classified beforehand (pixels whose rays cannot reach the scene box are settled when their
     grant is decoded; pixels whose rays all reach it skip the cull test) are scheduling matters: the accumulation, the
     framebuffer and the ray / path counters are the same bit for bit.  A 16:9 frame, so that both pixel classes and a band of
@@ -434,7 +445,7 @@ def test_sample_chunks(full, chunks):
         assert L.pt_set_sample_chunks(state.context, 1) == 0
 
 
-def test_deterministic_and_zero_copy(full):
+def test_deterministic_and_zero_copy(full, both_modes):
     """Same inputs -> same bits, and the ZERO_COPY framebuffer mode sees the same pixels."""
     state, obj, _ = full
     p = make_params(80, 60, 4, 5, True, True)
@@ -445,7 +456,7 @@ def test_deterministic_and_zero_copy(full):
     assert np.array_equal(f1, f2)
 
 
-def test_tile_partition_is_exact(full, oracle):
+def test_tile_partition_is_exact(full, oracle, both_modes):
     """Two ranks' pixel sets (sutil/WorkDistribution.h:60-81) are disjoint, cover the image, and their
     sum over a zero-initialised buffer equals the single-GPU launch bit for bit."""
     state, obj, _ = full
@@ -550,26 +561,29 @@ def test_windowed_stack_on_a_deep_tree(gpu_state_factory, oracle, tmp_path):
     p.cameraEye = _native.Float3(278.0, 273.0, -400.0)
     p.cameraU, p.cameraV, p.cameraW = _native.Float3(-2.0, 0.0, 0.0), _native.Float3(0.0, 2.0, 0.0), _native.Float3(0.0, 0.0, 400.0)
     ref, _, ref_st, _ = sc.render(copy_params(p), use_bvh=True)
-    imgs, moves = {}, 0
-    try:
-        for v_ in (9, 3, 0):                  # windowed stack / fp32 nodes, whole stack in LDS / segment-synchronous
-            assert L.pt_set_tuning(state.context, 0, v_) == 0, L.pt_last_error(state.context)
-            acc, fb, st = _gpu_render(state, p)
-            assert int(st[0].variant) == v_
-            imgs[v_] = (acc, (int(st[0].radiance_rays), int(st[0].shadow_rays)))
-            if v_ == 9:
-                d = (C.c_uint64 * 18)()
-                assert L.pt_debug_wf(state.context, d) == 0
-                moves = int(d[17])
-    finally:
-        assert L.pt_set_tuning(state.context, 0, _DEFAULT_VARIANT) == 0
-    print("windowed stack: %d wave-level moves between the LDS window and global memory; stack %d entries" % (moves, info.stack_entries))
-    assert moves > 0, "no ray outgrew the window: the test does not exercise what it is for"
-    for v_, (acc, cnt) in imgs.items():
-        assert np.array_equal(acc.view(np.uint32), imgs[0][0].view(np.uint32)), "variant %d differs from the segment-synchronous kernel" % v_
-        assert cnt == imgs[0][1], v_
-    assert image_mse(imgs[9][0], ref) < MSE_TOL
-    assert abs(imgs[9][1][0] - ref_st["radiance_rays"]) <= 2e-3 * ref_st["radiance_rays"]
+    for mode in ("ieee", "fast"):             # the oracle's level, and the library's default arithmetic
+        imgs, moves = {}, 0
+        try:
+            pt.setMathMode(state, mode)
+            for v_ in (9, 3, 0):              # windowed stack / fp32 nodes, whole stack in LDS / segment-synchronous
+                assert L.pt_set_tuning(state.context, 0, v_) == 0, L.pt_last_error(state.context)
+                acc, fb, st = _gpu_render(state, p)
+                assert int(st[0].variant) == v_
+                imgs[v_] = (acc, (int(st[0].radiance_rays), int(st[0].shadow_rays)))
+                if v_ == 9:
+                    d = (C.c_uint64 * 18)()
+                    assert L.pt_debug_wf(state.context, d) == 0
+                    moves = int(d[17])
+        finally:
+            assert L.pt_set_tuning(state.context, 0, _DEFAULT_VARIANT) == 0
+            pt.setMathMode(state, "ieee")
+        print("windowed stack (%s): %d wave-level moves between the LDS window and global memory; stack %d entries" % (mode, moves, info.stack_entries))
+        assert moves > 0, "no ray outgrew the window: the test does not exercise what it is for"
+        for v_, (acc, cnt) in imgs.items():
+            assert np.array_equal(acc.view(np.uint32), imgs[0][0].view(np.uint32)), "variant %d differs from the segment-synchronous kernel" % v_
+            assert cnt == imgs[0][1], v_
+        assert image_mse(imgs[9][0], ref) < MSE_TOL
+        assert abs(imgs[9][1][0] - ref_st["radiance_rays"]) <= 2e-3 * ref_st["radiance_rays"]
     sc.close()
 
 
@@ -888,7 +902,7 @@ def test_light_mode_scene_lights_and_mis(full, diffuse):
         assert np.array_equal(before.view(np.uint32), after.view(np.uint32))
 
 
-def test_full_size_properties(diffuse):
+def test_full_size_properties(diffuse, both_modes):
     """BASELINE config-2 geometry at its full 1920x1080 / 128 spp per launch: the oracle cannot follow
     at this size, so: (a) the segment-synchronous kernel and the default kernel agree bit for bit,
     counters included; (b) the 8-way tile partition sums to the whole image bit for bit; (c) counter
