@@ -16,8 +16,8 @@
 //   mats   : DevMaterial[n_mats]: pt_material (40 B, HitGroupData's payload, pathTracer.h:118-127) repacked at upload into two
 //            aligned 16-byte halves, {diffuse, ior} and {emission, bsdfType}; roughness and metallic, which the reference's
 //            shading ignores (:879-880), are not carried.
-// Compile with -ffp-contract=off: the only fused multiply-adds are the explicit ones in
-// tri_test(), which must match oracle/oracle_pt.cpp bit for bit.
+// Compile with -ffp-contract=off: the only fused multiply-adds are the explicit ones — in tri_test(), which must match
+// oracle/oracle_pt.cpp bit for bit, in the slab tests, and in the shading helpers at arithmetic level 2 (m_dot, m_cross, m_madd below).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
@@ -63,9 +63,9 @@ struct __attribute__((aligned(16))) HNode {
     uint4 b;
 };
 static_assert(sizeof(HNode) == 32, "hnode size");
-struct HSpace { float cx, cy, cz, inv_scale; };
+struct HSpace { float cx, cy, cz, inv_scale; };     // world = g * inv_scale + centre; inv_scale is a power of two
 constexpr uint32_t kTopNodeFlag = 0x40000000u;      // node reference into the breadth-first copy of the tree's top (DeviceScene::top)
-constexpr uint32_t kTopNodesMax = 255u;     // world = g * inv_scale + centre; inv_scale is a power of two
+constexpr uint32_t kTopNodesMax = 255u;
 
 // world -> grid: g = (w - origin) * inv_cell ; cell sizes per axis
 struct QGrid {

@@ -1,5 +1,6 @@
 // pt_shading.h — per-lane shading pieces shared by the render kernels: the reference's sampling,
-// BSDF and colour code restated for gfx950 (plain fp32, no contraction; citations inline).
+// BSDF and colour code restated for gfx950 (plain fp32; citations inline).  Every function takes the arithmetic level FM of
+// pt_device.h: 0 = IEEE operations without contraction, the oracle's level; 2 = the reference build's fast-math kind.
 #pragma once
 #include "pt_device.h"
 

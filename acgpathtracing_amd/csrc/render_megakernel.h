@@ -24,7 +24,7 @@ constexpr uint32_t kCounterWords = kCulledCounter + kTailCounters;
 // lane stacks would not fit a CU's LDS (trees deeper than ~28 levels), its large-scene twin: shade rounds at 24 parked lanes
 // instead of 40 and a sliding 16-entry stack window in LDS (profiles/r03_sweep_large_scenes.txt: 18 ... 24 % faster from 82 k to
 // 1.31 M triangles, 5 % slower at 20 k).  fp32 nodes otherwise, with triangle rounds at 8 lanes above kLargeSceneTris.
-constexpr int kVariantSync = 0, kVariantF32 = 1, kVariantF32Stats = 2, kVariantF32Large = 3, kVariantFastMath = 4;
+constexpr int kVariantSync = 0, kVariantF32 = 1, kVariantF32Stats = 2, kVariantF32Large = 3, kVariantTrig = 4;      // 4: the cosine sampler's trigonometry in hardware, rest as the math mode says
 constexpr int kVariantF16 = 5, kVariantF16Stats = 6, kVariantF16W5 = 7, kVariantLights = 8, kVariantF16W5Deep = 9;
 constexpr int kVariantWf = 10, kVariantWfStats = 11;      // the workgroup-level wavefront kernel (render_wavefront.hip) and its twin with time stamps
 constexpr int kDefaultVariant = kVariantF16W5;
