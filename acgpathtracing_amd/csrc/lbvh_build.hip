@@ -504,7 +504,7 @@ __global__ void k_centre_nodes(const BvhNode* __restrict__ nodes, uint32_t n, Bv
 }
 
 // --- 8. fp16 copy of the nodes -------------------------------------------------------------------------
-// Planes go to the scene-centred, power-of-two scaled space of HSpace and are rounded OUTWARD to fp16 (lo down, hi up),
+// Planes go to the scene-centred, scaled space of HSpace and are rounded OUTWARD to fp16 (lo down, hi up),
 // so every fp16 box contains its fp32 box.  area[0] / area[1] accumulate the child-box surface areas before / after, area[2] /
 // area[3] the number of boxes and the sum of their own after / before ratios: the measures by which pt_set_scene decides whether
 // the coarser planes are acceptable for this scene (render_megakernel.h kHalfAreaLimit, kHalfInflationLimit).
@@ -718,14 +718,17 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
     HIPCK(hipStreamSynchronize(stream));
     HIPCK(hipEventElapsedTime(&out.build_ms, sc.ev0, sc.ev1));
     for (int k = 0; k < 3; k++) { out.scene_lo[k] = ord2f(h_bounds[k]); out.scene_hi[k] = ord2f(h_bounds[3 + k]); }
-    {   // fp16 nodes: centre of the scene box, power-of-two scale that puts the farthest plane in [512, 1024)
+    {   // fp16 nodes: centre of the scene box, scaled so that the farthest plane sits at 1023
         float half_ext = 0.0f;
         HSpace sp;
         float* cc = &sp.cx;
         for (int k = 0; k < 3; k++) { cc[k] = 0.5f * out.scene_lo[k] + 0.5f * out.scene_hi[k]; half_ext = fmaxf(half_ext, fmaxf(out.scene_hi[k] - cc[k], cc[k] - out.scene_lo[k])); }
-        int e = 0;
-        (void)frexpf(half_ext > 0.0f && half_ext < INFINITY ? half_ext : 1.0f, &e);      // half_ext = m * 2^e, m in [0.5, 1)
-        sp.inv_scale = ldexpf(1.0f, e - 10);                                             // g = w * 2^(10 - e): |g| < 1024
+        // fp16 resolves 2^-11 of a value's own binade, so the rim of the scene should sit just BELOW a power of two: the farthest
+        // plane goes to 1023 (a power-of-two scale leaves it anywhere in [512, 1024): Cornell's 278 became 556, where a step is
+        // 0.5 — twice as coarse, 0.25 world units against 0.136 now).  Neither pack_planes() nor the kernels need the scale to be a
+        // power of two: its reciprocal's rounding and the product's (2^-23 of a coordinate) sit inside pack_planes' 2^-18 guard
+        // (test_gpu_fp16_slab_is_conservative runs both scales; profiles/r03_ab_hspace_scale.txt: -0.6 % / -0.3 % / 0 on configs 2 / 3 / 5).
+        sp.inv_scale = (half_ext > 0.0f && half_ext < INFINITY ? half_ext : 1.0f) / 1023.0f;
         float* d_area;
         float h_area[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         HIPCK(sc.alloc(&d_area, 16));

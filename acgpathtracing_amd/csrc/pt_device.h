@@ -52,8 +52,8 @@ struct __attribute__((aligned(16))) QNode {
 };
 static_assert(sizeof(QNode) == 32, "qnode size");
 
-// Half-precision node, 32 B = two 16-byte loads: each child box as six fp16 planes in a scene-centred, power-of-two
-// scaled space g = (w - centre) * scale, lo rounded down and hi rounded up so the fp16 box contains the fp32 one.
+// Half-precision node, 32 B = two 16-byte loads: each child box as six fp16 planes in a scene-centred, scaled
+// space g = (w - centre) * scale (the scene's farthest plane at 1023, where fp16 is finest relative to the scene), lo rounded down and hi rounded up so the fp16 box contains the fp32 one.
 //   a = { lo0.x | hi0.x << 16, lo0.y | hi0.y << 16, lo0.z | hi0.z << 16, child0 }
 //   b = { lo1.x | hi1.x << 16, lo1.y | hi1.y << 16, lo1.z | hi1.z << 16, child1 }
 // A slab plane is t = g * (1/d / scale) + (centre - o)/d: one v_fma_mix_f32 per plane, which reads the fp16 half of the
@@ -63,7 +63,7 @@ struct __attribute__((aligned(16))) HNode {
     uint4 b;
 };
 static_assert(sizeof(HNode) == 32, "hnode size");
-struct HSpace { float cx, cy, cz, inv_scale; };     // world = g * inv_scale + centre; inv_scale is a power of two
+struct HSpace { float cx, cy, cz, inv_scale; };     // world = g * inv_scale + centre; the builder puts the scene's farthest plane at g = 1023
 constexpr uint32_t kTopNodeFlag = 0x40000000u;      // node reference into the breadth-first copy of the tree's top (DeviceScene::top)
 constexpr uint32_t kTopNodesMax = 255u;
 
@@ -268,12 +268,13 @@ __device__ __forceinline__ float fma_h_lo(uint32_t packed, float a, float b) { r
 __device__ __forceinline__ float fma_h_hi(uint32_t packed, float a, float b) { return __builtin_fmaf((float)__builtin_bit_cast(half2_t, packed).y, a, b); }
 
 // ---- the slab test of the default render kernel on fp16 planes (NODE_FMT 9 of render_megakernel.hip) ----
-// pack_planes: builder side.  Planes go to the scene-centred, power-of-two scaled space of HSpace and are rounded OUTWARD.
+// pack_planes: builder side.  Planes go to the scene-centred, scaled space of HSpace and are rounded OUTWARD.
 __device__ __forceinline__ uint32_t half_bits(__half h) { return (uint32_t)__half_as_ushort(h); }
 __device__ __forceinline__ uint32_t pack_planes(float lo, float hi, float c, float scale, float& glo, float& ghi)
 {
     if (!(lo <= hi)) { glo = 0.0f; ghi = 0.0f; return 0x7C00u | (0xFC00u << 16); }      // empty child: lo = +inf, hi = -inf
-    // (w - c) * scale rounds twice in fp32 (2^-23 of the coordinate), and the render kernel's plane multiplier carries the ray's
+    // (w - c) * scale rounds twice in fp32, scale is the rounded reciprocal of the kernels' inv_scale and their plane multiplier
+    // (1/d) * inv_scale rounds once more (2^-22 of the coordinate together), and that multiplier carries the ray's
     // rotate flags in its five lowest mantissa bits (setup_ray, NODE_FMT 9: 2^-19 of the coordinate): each plane goes outward
     // by 2^-18 of its own coordinate before it is rounded outward to fp16 (whose step is 2^-11 of it)
     const float a = (lo - c) * scale, b = (hi - c) * scale;

@@ -103,7 +103,7 @@ __global__ void k_selftest(int op, const uint32_t* __restrict__ in, uint32_t n, 
     }
     if (op == 19) {
         // the default kernel's box test end to end: in = ray o xyz, d xyz, box lo xyz, hi xyz (fp32, as the builder holds it),
-        // scene centre xyz, inv_scale (a power of two), tmax; out = accepted (n <= min(f, tmax)), n, f.  The box goes through
+        // scene centre xyz, inv_scale, tmax; out = accepted (n <= min(f, tmax)), n, f.  The box goes through
         // pack_planes() (outward to fp16), the ray through setup_ray_h9(), the test is slab_h9() — what k_render_pw executes.
         const float* r = fin + 17 * i;
         HSpace hs; hs.cx = r[12]; hs.cy = r[13]; hs.cz = r[14]; hs.inv_scale = r[15];

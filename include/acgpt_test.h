@@ -44,7 +44,7 @@ int pt_bench_traversal(pt_ctx* ctx, const float* rays, size_t n, int repeats, in
  * and the default kernel's own ray / box test (no reference counterpart: OptiX traverses there), end to end:
  *   op 19 fp16 slab test: box -> outward fp16 planes, ray -> per-axis multiplier / addend with the rotate flags in the
  *         multiplier's low bits, entry / exit distance          in float[n][17] = ray o, d, box lo, hi, scene centre, inv_scale
- *         (a power of two), tmax    out uint32[n][3] = accepted, entry t (float bits), exit t (float bits).  Must accept every
+ *         (the builder's: scene half extent / 1023; any positive value), tmax    out uint32[n][3] = accepted, entry t (float bits), exit t (float bits).  Must accept every
  *         ray that meets the box shrunk by the builder's pad (tests/test_gpu_golden.py).
  * the arithmetic of PT_MATH_FAST (pt_set_math_mode; no reference vectors exist for it: nvcc's approximate instructions are not
  * reproducible here — the ops are held against their IEEE twins by error bounds):

@@ -9,6 +9,18 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+# PyTorch's ROCm wheel carries its own HIP / HSA runtime (torch/lib/libamdhip64.so, libhsa-runtime64.so); libacgpt_hip.so links
+# against /opt/rocm's.  With torch's runtime up first the two coexist (bench.py's order); in a process that used the library first,
+# a later torch.cuda.init() reports "No HIP GPUs are available" (measured on the GPU box: any pt_create before the first torch
+# call).  Tests that use torch next to the library (streams, lifetime, multi-rank) therefore need torch initialised before the first
+# context exists — whatever subset of the files is collected.  INTEGRATION.md section 5 states the same rule for callers.
+try:
+    import torch
+    torch.cuda.is_available()
+except Exception:       # no torch: those tests skip or fail on their own
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -271,16 +271,22 @@ def test_gpu_fp16_slab_is_conservative(ctx):
     keep = np.abs(d).max(axis=1) > 0
     d[~keep] = np.array([0.0, 1.0, 0.0], np.float32)
     tmax = np.where(rng.random(n) < 0.5, np.float32(1e16), (np.linalg.norm((target - o).astype(np.float64), axis=1) * rng.uniform(0.5, 1.5, n)).astype(np.float32)).astype(np.float32)
-    rec = np.concatenate([o, d, lo, hi, np.broadcast_to(centre, (n, 3)), np.full((n, 1), inv_scale, np.float32), tmax[:, None]], axis=1).astype(np.float32)
-    assert rec.shape == (n, 17)
-    out = np.zeros((n, 3), np.uint32)
-    run(ctx, 19, np.ascontiguousarray(rec), n, out)
-    accepted = out[:, 0] == 1
     must = _exact_slab(o, d, lo0, hi0, 0.01, tmax)
-    missed = must & ~accepted
     assert must.mean() > 0.3, "the case generator lost its hits"
-    assert not missed.any(), "box test rejected %d of %d rays that meet the unpadded box, first: %s" % (missed.sum(), must.sum(), rec[np.argmax(missed)])
-    # and it is a test, not a constant: rays that miss the box inflated by 2 % of the scene are (almost) never accepted
     wide = _exact_slab(o, d, lo - np.float32(0.02) * H, hi + np.float32(0.02) * H, 0.01, tmax)
     assert (~wide).mean() > 0.05
-    assert accepted[~wide].mean() < 1e-3, accepted[~wide].mean()
+    # the scale the builder uses — the scene's farthest plane goes to 1023, just below a power of two, where fp16 is finest
+    # relative to the scene (lbvh_build.hip) — and a power-of-two scale (round 2's rule: exact products, coarser planes)
+    half_ext = np.float32(np.abs(np.concatenate([lo, hi]) - centre).max())
+    for inv_scale in (np.float32(half_ext / np.float32(1023.0)), np.float32(2.0 ** (e - 10))):
+        rec = np.concatenate([o, d, lo, hi, np.broadcast_to(centre, (n, 3)), np.full((n, 1), inv_scale, np.float32), tmax[:, None]], axis=1).astype(np.float32)
+        assert rec.shape == (n, 17)
+        out = np.zeros((n, 3), np.uint32)
+        run(ctx, 19, np.ascontiguousarray(rec), n, out)
+        accepted = out[:, 0] == 1
+        missed = must & ~accepted
+        assert not missed.any(), "scale %r: box test rejected %d of %d rays that meet the unpadded box, first: %s" % (1.0 / inv_scale, missed.sum(), must.sum(), rec[np.argmax(missed)])
+        # and it is a test, not a constant: rays that miss the box inflated by 2 % of the scene are (almost) never accepted
+        assert accepted[~wide].mean() < 1e-3, accepted[~wide].mean()
+        print("fp16 slab test, planes scaled by %.4f: %.2f %% of the rays that miss the box inflated by 2 %% of the scene are accepted, %.1f %% of all rays"
+              % (1.0 / inv_scale, 100 * accepted[~wide].mean(), 100 * accepted.mean()))
