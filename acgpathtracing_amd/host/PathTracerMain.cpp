@@ -9,7 +9,10 @@
 //              [--max-depth 4] [--direct-lighting] [--importance-sampling] [--device 0]
 //              [--keys "0,1,UP,UP,R"] [--out frame.png] [--dump-every k] [--zero-copy]
 //              [--orbit dx,dy] [--zoom n] [--sample-chunks c] [--build-mode 0|1]
-//              [--gpus N] [--multi] [--save-accum file] [--restore-accum file]
+//              [--gpus N] [--multi] [--save-accum file] [--restore-accum file] [--light-mode 0|1] [--math fast|ieee]
+//
+// --math: arithmetic of the shading code (pt_set_math_mode).  fast (default) is what the reference's own build computes with —
+// nvcc --use_fast_math, /root/reference/CMakeLists.txt:267 —, ieee the correctly rounded level of the CPU oracle.
 //
 // --gpus N renders on devices 0..N-1 of the node through ONE context (pt_create_multi): pixel tiles of
 // sutil/WorkDistribution.h per device, one RCCL reduce of the accumulation per launch — the reference's dormant multi-GPU
