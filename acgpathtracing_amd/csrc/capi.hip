@@ -907,6 +907,11 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
         a.cull_lo = {c->bvh.scene_lo[0] - grow, c->bvh.scene_lo[1] - grow, c->bvh.scene_lo[2] - grow};
         a.cull_hi = {c->bvh.scene_hi[0] + grow, c->bvh.scene_hi[1] + grow, c->bvh.scene_hi[2] + grow};
     }
+    {   // origin-triangle release: the rounding of a hit point scales with the largest coordinate it can have
+        float cm = 0.0f;
+        for (int k = 0; k < 3; k++) cm = fmaxf(cm, fmaxf(fabsf(c->bvh.scene_lo[k]), fabsf(c->bvh.scene_hi[k])));
+        a.skip_base = ptd::kOriginEps * cm;
+    }
     a.row_spans = nullptr;
     if (c->pixel_classes && c->bvh.n_tris != 0u && p->height <= 32767u) {
         // recomputed only when the camera, the image size or the scene box change

@@ -181,6 +181,9 @@ struct Pending {
     f3 nxt_org, nxt_dir, radiance;
     float weight;     // NEE contribution factor if the shadow ray is unoccluded
     bool done;
+    // cosines of the shadow ray and of the next bounce against the plane of the triangle that was hit (0: unknown / not a ray
+    // that starts ON that triangle): what the origin-triangle release of the persistent kernel decides by
+    float cos_shadow = 0.0f, cos_bounce = 0.0f;
 };
 
 // __closesthit__diffuse__ch, pathTracerPrograms.cu:866-1031, for one lane.  Returns true when a
@@ -230,6 +233,7 @@ __device__ __forceinline__ bool shade_hit(const DeviceScene& sc, Late late, cons
         f3 w_in;
         if (late().useIS) w_in = FM >= 1 ? cosine_sample_hemisphere_fast<FM>(z1, z2) : cosine_sample_hemisphere(z1, z2);
         else         w_in = uniform_sample_hemisphere<FM>(z1, z2);
+        pd.cos_bounce = w_in.z;                                                  // cosine to the (flipped) geometric normal, before the change of basis
         onb_transform<FM>(N, w_in);
         pd.nxt_dir = w_in;
         pd.nxt_org = P;
@@ -276,6 +280,7 @@ __device__ __forceinline__ bool shade_hit(const DeviceScene& sc, Late late, cons
         const float nDl = m_dot<FM>(N, L);
         const float LnDl = -m_dot<FM>(mk(La.light.normal), L);
         want_shadow = nDl > 0.0f && LnDl > 0.0f;
+        pd.cos_shadow = nDl;
         pd.weight = m_div<FM>(nDl * LnDl * La.light_area, kPIf * Ldist * Ldist);         // :1021-1022 (|v1 x v2| from the host), used only if unoccluded
     }
     return want_shadow;

@@ -74,7 +74,12 @@ struct RenderArgs {
     const uint2* row_spans;
     uint32_t  row_interleave;     // 1 (experiment, pt_debug_queue_order): queue position -> tile-strip row 0, 8, 16, ..., 1, 9, ... so that every
     uint32_t  strip_rows;         // queue shard (one per XCD) holds rows from all over the image instead of a contiguous eighth
+    // origin-triangle release (render_megakernel.hip): a ray that leaves a triangle at cos(theta) to its plane cannot be accepted
+    // by that triangle's Moeller-Trumbore test once cos(theta) * tmin exceeds what rounding can put between the hit point and the
+    // plane: kOriginEps * (largest scene coordinate + length of the segment that produced the hit point).  skip_base = the first term.
+    float     skip_base;
 };
+constexpr float kOriginEps = 16.0f * 1.1920929e-7f;      // 16 * 2^-23
 
 int render_variant_count();
 const char* render_variant_name(int variant);

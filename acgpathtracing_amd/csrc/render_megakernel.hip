@@ -238,6 +238,11 @@ k_render_pw(const RenderArgsBox B)
     // kernel 10 % slower than the plain one on the same tree.
     constexpr bool WINDOW = STACK_CAP < 0;
     constexpr int FM = MATH ? 2 : (DIAG == 3 ? 1 : 0);         // arithmetic level of the shade phase
+    // Origin-triangle release (experiment, DIAG 5): a bounce or shadow ray starts ON the triangle its path has just hit and inside
+    // that triangle's box, so front-to-back traversal leads it to that leaf first, where it waits for a triangle round only to
+    // fail on t < tmin.  When cos(theta_out) * tmin exceeds the rounding between hit point and plane (RenderArgs::skip_base),
+    // Moeller-Trumbore cannot accept the origin triangle: a lane found sitting at that leaf when a trip ends moves on at once.
+    constexpr bool SKIP = DIAG == 5 && INNER >= 1 && !LIGHTS;
     constexpr int WIN = WINDOW ? -STACK_CAP : 0;
     static_assert(!WINDOW || ((WIN & (WIN - 1)) == 0 && WIN >= 16), "the window wraps by masking and must hold two trips");
     const uint32_t lds_entries = WINDOW ? (uint32_t)WIN + 1u : ((STACK_CAP > 0 && A.stack_entries > (uint32_t)STACK_CAP) ? (uint32_t)STACK_CAP : A.stack_entries);   // WINDOW: entry WIN of a lane's column holds its window base
@@ -322,6 +327,8 @@ k_render_pw(const RenderArgsBox B)
     // origin P (diffuse) or P + R * 1e-4 (conductor, :948) and is recomputed with the closest-hit's operations.
     Pending pd_lights; pd_lights.nxt_org = mk(0.0f); pd_lights.nxt_dir = mk(0.0f, 0.0f, 1.0f); pd_lights.radiance = mk(0.0f); pd_lights.weight = 0.0f; pd_lights.done = true;   // LIGHTS only: the whole record
     f3 keep_dir = mk(0.0f, 0.0f, 1.0f); float keep_weight = 0.0f; bool keep_done = true, keep_metal = false;
+    int origin_ref = kSentinel;                       // SKIP: leaf reference of the triangle the ray in flight starts on
+    bool skip_now = false, keep_skip = false;         // ... may the ray in flight / the bounce after the shadow ray pass it by
 
     for (;;) {
         // =========================== shade / regenerate: lanes with no ray in flight ===============
@@ -329,6 +336,7 @@ k_render_pw(const RenderArgsBox B)
         const auto late = [&]() -> const RenderArgs& { return B.a[opaque_zero()]; };
         if (STATS) { n_rounds += 1; n_lane_rounds += (unsigned long long)popc(vote(lp.alive && node == kSentinel)); t_phase = __builtin_amdgcn_s_memrealtime(); }
         bool segment_done = false, started_shadow = false;
+        bool skip_bounce = false;                                     // SKIP: may the bounce that starts in this round pass its origin triangle by
         f3 emission = mk(0.0f);
         Pending pd;                                                   // lives within one shade round (light mode 1: carried in pd_lights)
         if (LIGHTS) pd = pd_lights;
@@ -345,6 +353,7 @@ k_render_pw(const RenderArgsBox B)
                 }
                 shadow_ray = false;
                 segment_done = true;
+                skip_bounce = keep_skip;
             } else {                                                  // radiance ray back
                 bool want_shadow = false;
                 f3 P, L; float Ldist;
@@ -355,6 +364,13 @@ k_render_pw(const RenderArgsBox B)
                     pd.radiance = mk(0.0f); pd.weight = 0.0f; pd.done = true;
                 }
                 lp.result += emission;                                // :760 (before the radiance term)
+                if (SKIP) {
+                    // the rays that start at this hit point: cos(theta_out) * tmin against the rounding between P and the triangle's plane
+                    const float bound = late().skip_base + kOriginEps * best_t;
+                    origin_ref = best_slot >= 0 ? ~best_slot : kSentinel;
+                    skip_bounce = best_slot >= 0 && pd.cos_bounce * 0.01f > bound;
+                    if (want_shadow) { skip_now = pd.cos_shadow * 0.01f > bound; keep_skip = skip_bounce; }
+                }
                 if (want_shadow) {
                     if (LIGHTS) pd_lights = pd;
                     else {
@@ -385,6 +401,7 @@ k_render_pw(const RenderArgsBox B)
                 att = roulette_scale<FM>(att, p);
                 ro = pd.nxt_org; rd = pd.nxt_dir;
                 ++depth;
+                if (SKIP) skip_now = skip_bounce;
             } else {
                 lp.samples_left--;
                 lp.new_path = true;
@@ -438,6 +455,7 @@ k_render_pw(const RenderArgsBox B)
                 prev_pdf = 0.0f;
                 lp.new_path = false;
                 start_radiance = true;
+                if (SKIP) skip_now = false;                       // a camera ray starts on no triangle
             }
         }
         if (vote(my_culled != 0u) != 0ull) {                           // wave sum of the per-lane counts, bit plane by bit plane
@@ -708,6 +726,13 @@ k_render_pw(const RenderArgsBox B)
                         sp = sp ? sp - 1 : 0;
                         tos = pop(sp);
                     }
+                }
+            }
+            if (SKIP) {
+                if (skip_now && node == origin_ref) {     // sitting at the triangle the ray started on: it cannot be hit (see SKIP above)
+                    node = sp ? tos : kSentinel;
+                    sp = sp ? sp - 1 : 0;
+                    tos = pop(sp);
                 }
             }
             const bool at_leaf = node < 0;       // kSentinel is positive
