@@ -785,6 +785,12 @@ def _headline_check(gpu_state_factory, oracle, scene, depth, frames, windows, la
     c_i, c_f = sum(int(t.culled_rays) for t in st), sum(int(t.culled_rays) for t in fst)
     assert abs(c_i - c_f) <= 1e-5 * max(1, c_i), (c_i, c_f)     # a camera ray within rounding of the box's silhouette may fall either way
     assert np.isfinite(facc).all() and np.all(facc[..., 3] == 1.0)
+    # the two math modes over the WHOLE 1920x1080 frame (the oracle follows on windows only): the same image
+    whole = image_mse(facc, acc)
+    m_i, m_f = float(acc[..., :3].mean()), float(facc[..., :3].mean())
+    print("%s, whole frame: fast vs ieee MSE %.3e, means %.6f / %.6f, %.1f %% of the pixels bit-identical" %
+          (label, whole, m_i, m_f, 100 * float(np.all(acc.view(np.uint32) == facc.view(np.uint32), axis=-1).mean())))
+    assert whole < 1e-7 and abs(m_i - m_f) <= 1e-4 * m_i, (whole, m_i, m_f)
     worst = 0.0
     for name, (x0, y0, ww, wh) in windows.items():
         ref = None
