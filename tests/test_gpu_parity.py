@@ -529,13 +529,18 @@ def test_edge_cases(gpu_state_factory, oracle, tmp_path):
     ref, _, _, _ = sc.render(copy_params(p), use_bvh=False)
     assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32))
     assert acc[..., :3].max() > 1.0          # Ke + Ke*Kd seen directly
-    # empty scene: every ray misses, image is black with alpha 1
+    with _math(state, "fast"):               # the default arithmetic: the emitter is the only surface, every value is Ke + Ke * Kd or 0
+        facc, _, fst = _gpu_render(state, p)
+    assert image_mse(facc, ref) < MSE_TOL and np.array_equal(facc[..., :3] > 0, ref[..., :3] > 0) and fst[0].math_mode == _native.MATH_FAST
+    # empty scene: every ray misses, image is black with alpha 1 — in both math modes
     v = np.zeros(4, np.float32)
     assert L.pt_set_scene(state.context, v.ctypes.data, 1, None, 0, None, None, 0) == 0
     state.params.handle = L.pt_scene_handle(state.context)
-    acc, fb, st = _gpu_render(state, p)
-    assert np.all(acc[..., :3] == 0.0) and np.all(acc[..., 3] == 1.0) and np.all(fb[..., :3] == 0) and np.all(fb[..., 3] == 255)
-    assert st[0].radiance_rays == 32 * 32 * 2
+    for mode in ("ieee", "fast"):
+        with _math(state, mode):
+            acc, fb, st = _gpu_render(state, p)
+        assert np.all(acc[..., :3] == 0.0) and np.all(acc[..., 3] == 1.0) and np.all(fb[..., :3] == 0) and np.all(fb[..., 3] == 255)
+        assert st[0].radiance_rays == 32 * 32 * 2
     # argument checking (PathTracerMain.cpp:42, 122-128; pathTracerPrograms.cu:727)
     for field, bad in (("maxDepth", 0), ("maxDepth", 29), ("samplesPerPixel", 0), ("width", 0), ("height", 70000)):
         q = copy_params(state.params)
