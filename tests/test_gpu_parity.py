@@ -915,6 +915,11 @@ def test_light_mode_scene_lights_and_mis(full, diffuse):
                 assert np.isfinite(acc).all() and mse < MSE_TOL and same > 0.60
                 assert abs(int(st[0].radiance_rays) - ref_st["radiance_rays"]) <= 2e-3 * ref_st["radiance_rays"]
                 assert abs(int(st[0].shadow_rays) - ref_st["shadow_rays"]) <= 2e-3 * max(1, ref_st["shadow_rays"])
+                with _math(state, "fast"):                         # the LIGHTS kernel's fast-math twin: by tolerance
+                    facc, _, fst = _gpu_render(state, p)
+                assert b"LIGHTS" in L.pt_variant_name(int(fst[0].variant)) and fst[0].math_mode == _native.MATH_FAST and fst[0].paths == st[0].paths
+                fmse = image_mse(facc, ref) if isamp else image_mse_trimmed(facc, ref, FLIP_DROP)
+                assert np.isfinite(facc).all() and fmse < MSE_TOL and image_mse(facc, ref) < MSE_TOL_FLIPS, (name, dl, isamp, fmse, image_mse(facc, ref))
             if name == "diffuse":                                  # (b) 48 x 36 pixels x 1024 spp: image means
                 means = {}
                 for mode in (1, 0):
