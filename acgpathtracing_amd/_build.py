@@ -14,7 +14,8 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 HOST = os.path.join(PKG, "host")
 
-HIP_SOURCES = ["capi.hip", "lbvh_build.hip", "wide_bvh.hip", "render_megakernel.hip", "render_wavefront.hip", "selftest.hip"]
+HIP_SOURCES = ["capi.hip", "lbvh_build.hip", "wide_bvh.hip", "render_megakernel.hip", "selftest.hip"]
+EXPERIMENT_SOURCES = ["render_wavefront.hip"]      # kernels that were measured and lost: libacgpt_hip_exp.so only
 HIP_HEADERS = ["pt_device.h", "pt_shading.h", "lbvh_build.h", "render_megakernel.h", "render_common.h", "render_experiments.inc", "selftest.h"]
 HOST_SOURCES = ["host_capi.cpp", "TinyObjWrapper.cpp", "Camera.cpp", "Trackball.cpp", "ImageIO.cpp"]
 
@@ -37,7 +38,7 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
-KERNEL_SOURCES = ["render_megakernel.hip", "render_wavefront.hip", "render_megakernel.h", "render_common.h", "pt_device.h", "pt_shading.h"]
+KERNEL_SOURCES = ["render_megakernel.hip", "render_megakernel.h", "render_common.h", "pt_device.h", "pt_shading.h", "lbvh_build.hip", "lbvh_build.h"]
 
 
 def kernel_source_hash():
@@ -57,7 +58,7 @@ def build_hip(force=False, verbose=False, experiments=False):
     not adopted (-DACGPT_EXPERIMENTS; tools/sweep_variants.py loads it via ACGPT_EXPERIMENTS=1).  Never the product.
     By default only the current round's experiments are compiled in; ACGPT_EXPERIMENTS_ALL=1 adds the ~70 of earlier rounds."""
     out = os.path.join(PKG, "libacgpt_hip_exp.so" if experiments else "libacgpt_hip.so")
-    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES + (EXPERIMENT_SOURCES if experiments else [])]
     deps = srcs + [os.path.join(CSRC, h) for h in HIP_HEADERS] + [os.path.join(ROOT, "include", "acgpt.h"), os.path.join(ROOT, "include", "acgpt_test.h")]
     if force or _stale(out, deps):
         cmd = [_hipcc()] + HIP_FLAGS + (["-DACGPT_EXPERIMENTS=%d" % (2 if os.environ.get("ACGPT_EXPERIMENTS_ALL") == "1" else 1)] if experiments else []) + \

@@ -76,7 +76,7 @@ ABI_SYMBOLS = [
     "pt_host_malloc_mapped", "pt_host_free_mapped", "pt_abi_version",
 ]
 # ... and include/acgpt_test.h (test hooks and diagnostics; same library)
-TEST_SYMBOLS = ["pt_bench_traversal", "pt_selftest", "pt_debug_wave_times", "pt_debug_queue_progress", "pt_debug_wf", "pt_debug_queue_order", "pt_debug_pixel_classes", "pt_debug_row_spans", "pt_read_morton"]
+TEST_SYMBOLS = ["pt_bench_traversal", "pt_selftest", "pt_debug_wave_times", "pt_debug_queue_progress", "pt_debug_window_moves", "pt_debug_queue_order", "pt_debug_pixel_classes", "pt_debug_row_spans", "pt_read_morton"]
 
 _hip = None
 _host = None
@@ -136,7 +136,9 @@ def hip():
     L.pt_debug_wave_times.argtypes = [vp, vp, sz]; L.pt_debug_wave_times.restype = C.c_int
     L.pt_debug_queue_progress.argtypes = [vp, vp]; L.pt_debug_queue_progress.restype = C.c_int
     L.pt_read_morton.argtypes = [vp, vp, vp]; L.pt_read_morton.restype = C.c_int
-    L.pt_debug_wf.argtypes = [vp, vp]; L.pt_debug_wf.restype = C.c_int
+    L.pt_debug_window_moves.argtypes = [vp, vp]; L.pt_debug_window_moves.restype = C.c_int
+    if hasattr(L, "pt_debug_wf"):      # experiments library only
+        L.pt_debug_wf.argtypes = [vp, vp]; L.pt_debug_wf.restype = C.c_int
     L.pt_debug_queue_order.argtypes = [vp, C.c_int]; L.pt_debug_queue_order.restype = C.c_int
     L.pt_debug_pixel_classes.argtypes = [vp, C.c_int]; L.pt_debug_pixel_classes.restype = C.c_int
     L.pt_debug_row_spans.argtypes = [C.POINTER(PathTraceParams), vp, vp, vp]; L.pt_debug_row_spans.restype = C.c_int

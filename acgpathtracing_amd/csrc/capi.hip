@@ -989,12 +989,14 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
     { Range range("acgpt: render megakernel (launch_batch)"); CK(c, ptd::launch_render(variant, c->math_mode, a, grid, c->stream)); }
     CK(c, hipEventRecord(c->ev1, c->stream));
     { Range range("acgpt: k_finalize"); CK(c, ptd::launch_finalize(a, c->stream)); }
-    unsigned long long h[8], h_tail[2] = {0, 0};
+    unsigned long long h[8], h_tail[2] = {0, 0};      // h_tail: culled camera rays; experiments build: workgroups of a wavefront kernel that gave up
     CK(c, hipMemcpyAsync(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     CK(c, hipMemcpyAsync(h_tail, c->d_counters + ptd::kCulledCounter, sizeof(h_tail), hipMemcpyDeviceToHost, c->stream));
     CK(c, hipStreamSynchronize(c->stream));            // CUDA_SYNC_CHECK, PathTracerMain.cpp:209
     const unsigned long long h_culled = h_tail[0];
+#ifdef ACGPT_EXPERIMENTS
     if (h_tail[1] != 0) return fail(c, "pt_launch: the render kernel gave up (" + std::to_string(h_tail[1]) + " workgroups: scheduling error or watchdog); the image is incomplete");
+#endif
     float ms = 0.0f;
     CK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->stats.radiance_rays = h[0];
@@ -1191,14 +1193,24 @@ PT_API int pt_debug_pixel_classes(pt_ctx* c, int on)
     return 0;
 }
 
+PT_API int pt_debug_window_moves(pt_ctx* c, uint64_t* out)
+{
+    if (!c || !out) return fail(c, "pt_debug_window_moves: null argument");
+    CK(c, hipSetDevice(c->device));
+    CK(c, hipMemcpy(out, c->d_counters + ptd::kWindowMoves, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+#ifdef ACGPT_EXPERIMENTS
+// experiments build only: per-role times of the last launch of a wavefront kernel (render_wavefront.hip), 17 values (tools/wf_check.py)
 PT_API int pt_debug_wf(pt_ctx* c, uint64_t* out)
 {
     if (!c || !out) return fail(c, "pt_debug_wf: null argument");
     CK(c, hipSetDevice(c->device));
     CK(c, hipMemcpy(out, c->d_counters + ptd::kWfDiag, 17 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    CK(c, hipMemcpy(out + 17, c->d_counters + ptd::kWindowMoves, sizeof(uint64_t), hipMemcpyDeviceToHost));
     return 0;
 }
+#endif
 
 PT_API int pt_read_morton(pt_ctx* c, uint32_t* codes_sorted, uint32_t* prims_sorted)
 {

@@ -346,10 +346,12 @@ __device__ __forceinline__ uint32_t opaque_zero() { uint32_t z; asm volatile("s_
 
 // ---- host-side interface of the kernel translation units --------------------------------------------------------------------
 typedef void (*RenderKernel)(const RenderArgsBox);
-// workgroup-level wavefront kernels (render_wavefront.hip)
+#ifdef ACGPT_EXPERIMENTS
+// workgroup-level wavefront kernels (render_wavefront.hip; measured, lost, experiments build only)
 struct WfDesc { RenderKernel k; int nt, ns, pool, stack_cap; const char* name; const char* kernel; RenderKernel k_fast; const char* kernel_fast; };
 int wf_variant_count();
 const WfDesc* wf_variant(int i);
 size_t wf_lds_bytes(const WfDesc& d, uint32_t stack_entries);
+#endif
 
 }  // namespace ptd

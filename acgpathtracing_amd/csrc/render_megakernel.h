@@ -11,9 +11,13 @@ constexpr uint32_t kMaxTimedWaves = 16384;   // stats variants stamp start / que
 // layout of RenderArgs::counters (64-bit words): [0, 8) ray / path / scheduler counters, [8, 8 + 3 * kMaxTimedWaves) wave stamps,
 // then 2056 words of queue progress and phase times (stats variants), then kTailCounters more launch counters
 constexpr uint32_t kCulledCounter = 8u + 3u * kMaxTimedWaves + 2056u;   // camera rays ended by the scene-box cull (they are part of counters[0] and [2] too)
-constexpr uint32_t kAbortCounter = kCulledCounter + 1u;                 // workgroups of a wavefront kernel that gave up (scheduling error or watchdog): the launch fails
+#ifdef ACGPT_EXPERIMENTS
+constexpr uint32_t kAbortCounter = kCulledCounter + 1u;                 // workgroups of a wavefront kernel (experiments build) that gave up (scheduling error or watchdog): the launch fails
+#endif
 constexpr uint32_t kWindowMoves = kCulledCounter + 20u;  // wave-level moves of stack entries between the LDS window and global memory (windowed-stack kernels)
-constexpr uint32_t kWfDiag = kCulledCounter + 2u;      // 12 words of wavefront-kernel diagnostics (render_wavefront.hip, pt_debug_wf)
+#ifdef ACGPT_EXPERIMENTS
+constexpr uint32_t kWfDiag = kCulledCounter + 2u;      // 17 words of wavefront-kernel diagnostics (render_wavefront.hip, pt_debug_wf; experiments build)
+#endif
 constexpr uint32_t kTailCounters = 24u;
 constexpr uint32_t kCounterWords = kCulledCounter + kTailCounters;
 // Variant indices of the product library (render_megakernel.hip kVariants).  pt_set_scene picks one per scene unless
@@ -26,7 +30,9 @@ constexpr uint32_t kCounterWords = kCulledCounter + kTailCounters;
 // 1.31 M triangles, 5 % slower at 20 k).  fp32 nodes otherwise, with triangle rounds at 8 lanes above kLargeSceneTris.
 constexpr int kVariantSync = 0, kVariantF32 = 1, kVariantF32Stats = 2, kVariantF32Large = 3, kVariantTrig = 4;      // 4: the cosine sampler's trigonometry in hardware, rest as the math mode says
 constexpr int kVariantF16 = 5, kVariantF16Stats = 6, kVariantF16W5 = 7, kVariantLights = 8, kVariantF16W5Deep = 9;
-constexpr int kVariantWf = 10, kVariantWfStats = 11;      // the workgroup-level wavefront kernel (render_wavefront.hip) and its twin with time stamps
+#ifdef ACGPT_EXPERIMENTS
+constexpr int kVariantWf = 10, kVariantWfStats = 11;      // experiments build: the workgroup-level wavefront kernel (render_wavefront.hip) and its twin with time stamps
+#endif
 constexpr int kDefaultVariant = kVariantF16W5;
 constexpr uint32_t kLargeSceneTris = 100000;
 constexpr uint32_t kWindowSceneTris = 50000;

@@ -1171,7 +1171,7 @@ hipError_t trace_stream_occupancy(int fmt, uint32_t stack_entries, int* blocks_p
 // ---- host-side launchers ------------------------------------------------------------------
 // k / kernel: the instantiation with IEEE arithmetic in the shading code; k_fast / kernel_fast: its twin with the arithmetic of the
 // reference's own build (pt_set_math_mode; nullptr: the variant exists at the IEEE level only — experiment rows)
-struct VariantDesc { RenderKernel k; int threads; int node_fmt; const char* name; int stack_cap = 0; const char* kernel = ""; int wf = -1; int top_n = 0; RenderKernel k_fast = nullptr; const char* kernel_fast = ""; };   // wf >= 0: index into render_wavefront.hip's table
+struct VariantDesc { RenderKernel k; int threads; int node_fmt; const char* name; int stack_cap = 0; const char* kernel = ""; int wf = -1; int top_n = 0; RenderKernel k_fast = nullptr; const char* kernel_fast = ""; };   // wf >= 0 (experiments build only): index into render_wavefront.hip's table
 
 // Render kernel variants.  0: segment-synchronous (fp32 nodes).  Others: persistent traversal
 // <SHADE_K, LEAF_K, NODE_FMT, THREADS, MINW, STATS, DIAG, INNER, LEAVES, LIGHTS, STACK_CAP, TOPN>.  The product library carries the
@@ -1194,8 +1194,6 @@ static const VariantDesc kVariants[] = {
     ROW(256, 9, "pw K40 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes with the rotate amounts in the multipliers' low bits, FIVE waves per SIMD (96 registers), five visits and two triangle tests per loop trip", 0, 40, 16, 9, 256, 5, false, 0, 5, 2, false, 0, 0),
     ROW(256, 9, "LIGHTS scene-driven area lights + MIS (light mode 1, opt-in: not the reference's estimator), fp16 sign-rotated nodes w4", 0, 44, 16, 9, 256, 4, false, 0, 5, 2, true, 0, 0),
     ROW(256, 9, "pw K24 L16 fp16 sign-rotated nodes, five waves per SIMD, for large scenes and deep trees: shade rounds at 24 parked lanes (rays are long there), a sliding window of 16 stack entries per lane in LDS, deeper ones moved to global memory four at a time", -16, 24, 16, 9, 256, 5, false, 0, 5, 2, false, -16, 0),
-    {nullptr, 0, 9, nullptr, 0, nullptr, 0},      // kVariantWf: filled from render_wavefront.hip's table (variant_desc)
-    {nullptr, 0, 9, nullptr, 0, nullptr, 1},      // kVariantWfStats
 #ifdef ACGPT_EXPERIMENTS
 #include "render_experiments.inc"
 #endif
@@ -1205,11 +1203,13 @@ int render_variant_count() { return (int)(sizeof(kVariants) / sizeof(kVariants[0
 static VariantDesc variant_desc(int v)
 {
     VariantDesc d = kVariants[v];
+#ifdef ACGPT_EXPERIMENTS
     if (d.wf >= 0) {
         const WfDesc* w = wf_variant(d.wf);
         d.k = w->k; d.threads = (w->nt + w->ns) * 64; d.name = w->name; d.stack_cap = w->stack_cap; d.kernel = w->kernel;
         d.k_fast = w->k_fast; d.kernel_fast = w->kernel_fast;
     }
+#endif
     return d;
 }
 // the instantiation a math mode runs: the fast twin where the variant has one (experiment rows exist at the IEEE level only)
@@ -1229,7 +1229,9 @@ int render_variant_has_fast_math(int v) { return (v >= 0 && v < render_variant_c
 
 static size_t variant_lds(const VariantDesc& d, uint32_t stack_entries, uint32_t n_nodes)
 {
+#ifdef ACGPT_EXPERIMENTS
     if (d.wf >= 0) return wf_lds_bytes(*wf_variant(d.wf), stack_entries);
+#endif
     if (d.stack_cap > 0 && stack_entries > (uint32_t)d.stack_cap) stack_entries = (uint32_t)d.stack_cap;
     if (d.stack_cap < 0) stack_entries = (uint32_t)(-d.stack_cap) + 1u;      // sliding window: that many entries, whatever the tree, + the window base
     size_t lds = (size_t)(d.threads / 64) * (stack_entries * 256u + kBookDwords * 4u) + 256u + (size_t)d.top_n * sizeof(HNode);      // lane stacks, fold bookkeeping, LCG skip-ahead table, staged top of the tree

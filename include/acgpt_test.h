@@ -72,11 +72,16 @@ int pt_debug_pixel_classes(pt_ctx* ctx, int on);
  * [box_lo, box_hi], out[2 * y] = outer columns lo | hi << 16 and out[2 * y + 1] = inner columns lo | hi << 16 of image row y
  * (2 * height words).  0 = computed, 1 = no classes for this view (box not entirely in front of the eye, degenerate frame). */
 int pt_debug_row_spans(const pt_params* params, const float* box_lo, const float* box_hi, uint32_t* out);
-/* Diagnostic: 18 values of the last launch.  [17]: a windowed-stack kernel's moves of stack entries between the LDS window and
- * global memory (wave-level events).  [0..16]: after a launch of a wavefront kernel variant (render_wavefront.hip), summed over the waves of the grid,
- * times in 10 ns ticks: trace waves {total, idle}, shade waves {total, idle, deal time / rounds / records, hit-shading time /
- * rounds / records, accounting time / rounds / records}, trace waves {exchange time / exchanges / records taken in, loop trips}. */
+/* Diagnostic, one value of the last launch: a windowed-stack kernel's moves of stack entries between the LDS window and global
+ * memory (wave-level events; 0 for the kernels that keep the whole stack in LDS). */
+int pt_debug_window_moves(pt_ctx* ctx, uint64_t* out);
+#ifdef ACGPT_EXPERIMENTS
+/* Experiments library only (libacgpt_hip_exp.so, -DACGPT_EXPERIMENTS; never the product): 17 values after a launch of a wavefront
+ * kernel variant (render_wavefront.hip), summed over the waves of the grid, times in 10 ns ticks: trace waves {total, idle},
+ * shade waves {total, idle, deal time / rounds / records, hit-shading time / rounds / records, accounting time / rounds /
+ * records}, trace waves {exchange time / exchanges / records taken in, loop trips}. */
 int pt_debug_wf(pt_ctx* ctx, uint64_t* out);
+#endif
 /* Sorted (morton, triangle) pairs of the last build, HOST outputs of n_tris. */
 int pt_read_morton(pt_ctx* ctx, uint32_t* codes_sorted, uint32_t* prims_sorted);
 

@@ -22,6 +22,7 @@ def lib():
 def header_symbols(name="acgpt.h"):
     text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"#ifdef ACGPT_EXPERIMENTS.*?#endif", "", text, flags=re.S)      # declared for libacgpt_hip_exp.so only: the product must NOT export them
     return sorted(set(re.findall(r"\b(pt_[a-z_]+)\s*\(", text)))
 
 

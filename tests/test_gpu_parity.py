@@ -597,9 +597,9 @@ def test_windowed_stack_on_a_deep_tree(gpu_state_factory, oracle, tmp_path):
                 assert int(st[0].variant) == v_
                 imgs[v_] = (acc, (int(st[0].radiance_rays), int(st[0].shadow_rays)))
                 if v_ == 9:
-                    d = (C.c_uint64 * 18)()
-                    assert L.pt_debug_wf(state.context, d) == 0
-                    moves = int(d[17])
+                    d = (C.c_uint64 * 1)()
+                    assert L.pt_debug_window_moves(state.context, d) == 0
+                    moves = int(d[0])
         finally:
             assert L.pt_set_tuning(state.context, 0, _DEFAULT_VARIANT) == 0
             pt.setMathMode(state, "ieee")

@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""Quick A/B of the wavefront kernels against the default kernel: same bits, kernel times.
-usage: tools/wf_check.py [width height spp frames depth] (GPU box)"""
+"""Quick A/B of the wavefront kernels against the default kernel: same bits, kernel times.  The wavefront kernels were measured and
+lost; they live in the experiments library only (libacgpt_hip_exp.so: _build.build_hip(experiments=True)), which
+this tool loads.  usage: tools/wf_check.py [width height spp frames depth] (GPU box)"""
 import os
 import sys
+
+os.environ.setdefault("ACGPT_EXPERIMENTS", "1")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -52,8 +55,8 @@ for chunks in chunk_list:
             line += "  bits %s counters %s" % ("SAME" if same else "DIFFER (%d pixels, max abs %.3e)" % (int(np.any(acc != ref[0], axis=-1).sum()), float(np.abs(acc - ref[0]).max())), "same" if cnt == ref[1] else "DIFFER")
             ok = ok and same and cnt == ref[1]
         print(line, flush=True)
-        if st.variant >= 10:
-            d = (C.c_uint64 * 18)()
+        if st.variant >= 10 and hasattr(L, "pt_debug_wf"):
+            d = (C.c_uint64 * 17)()
             L.pt_debug_wf(state.context, d)
             d = [int(x) for x in d]
             tt, ti, stt, si = d[0], d[1], d[2], d[3]

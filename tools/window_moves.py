@@ -14,8 +14,8 @@ state.params.accumulationBuffer, state.params.handle = keep_a, keep_h
 state.params.currentFrameIdx = 0
 assert L.pt_launch_frames(state.context, C.byref(state.params), 2) == 0
 st = pt.getStats(state)
-d = (C.c_uint64 * 18)(); L.pt_debug_wf(state.context, d)
+d = (C.c_uint64 * 1)(); L.pt_debug_window_moves(state.context, d)
 rays = int(st.radiance_rays + st.shadow_rays - st.culled_rays)
 print("variant %d, %.1f ms, %d traversed rays, %d wave-level window moves (each moves 4 entries of up to 64 lanes: <= %.1f MB), moves per 1000 rays %.3f"
-      % (st.variant, st.kernel_ms, rays, int(d[17]), int(d[17]) * 1024 / 1e6, 1000.0 * int(d[17]) / rays))
+      % (st.variant, st.kernel_ms, rays, int(d[0]), int(d[0]) * 1024 / 1e6, 1000.0 * int(d[0]) / rays))
 pt.CleanAllTheThings(state)
