@@ -96,6 +96,27 @@ def host_library_path():
     return os.path.join(PKG, "libacgpt_host.so")
 
 
+def _torch_first():
+    """The load-order rule of INTEGRATION.md section 5, enforced instead of documented only.  PyTorch's ROCm wheel carries its own
+    HIP / HSA runtime; libacgpt_hip.so links against /opt/rocm's.  With torch's runtime up first the two coexist; in a process
+    that loaded this library first, a later torch.cuda.init() reports "No HIP GPUs are available".  So, before the library is
+    loaded: a torch that is already imported gets its GPU side initialised; a torch that is installed but not imported yet is
+    imported and initialised (ACGPT_TORCH_FIRST=1, the default), left alone (=0: a process that will never use torch and does
+    not want the import), or refused with the reason (=error)."""
+    import importlib.util
+    import sys
+    mode = os.environ.get("ACGPT_TORCH_FIRST", "1")
+    if "torch" not in sys.modules:
+        if mode == "0" or importlib.util.find_spec("torch") is None:
+            return
+        if mode == "error":
+            raise RuntimeError("libacgpt_hip.so is about to be loaded before PyTorch's GPU runtime: `import torch; torch.cuda.is_available()` "
+                               "must come first in a process that uses both (INTEGRATION.md section 5), or set ACGPT_TORCH_FIRST=0 "
+                               "if this process never touches torch.cuda")
+    import torch
+    torch.cuda.is_available()
+
+
 def hip():
     """The HIP library.  Raises if it is not built or cannot be loaded (no fallback)."""
     global _hip
@@ -104,6 +125,7 @@ def hip():
     path = hip_library_path()
     if not os.path.exists(path):
         raise RuntimeError("libacgpt_hip.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+    _torch_first()
     L = C.CDLL(path)
     vp, sz, u32p, f32p = C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_float)
     L.pt_create.argtypes = [C.POINTER(vp), C.c_int]; L.pt_create.restype = C.c_int

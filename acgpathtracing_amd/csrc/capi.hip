@@ -2,7 +2,16 @@
 // Each export names the reference function it stands in for (see acgpt.h).  There is no
 // CPU path in this library: every entry point fails if no HIP device is usable.
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>      // types only: librccl is loaded with dlopen by pt_create_multi, a single-GPU caller never touches it
+// RCCL: types only — librccl is loaded with dlopen by pt_create_multi, a single-GPU caller never touches it, and a box without
+// the RCCL headers still builds the library (the handful of types and enumerators used below, with rccl.h's values)
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+#endif
 #include <dlfcn.h>
 #include <algorithm>
 #include <chrono>
@@ -126,7 +135,7 @@ struct RcclApi {
 struct pt_multi {
     std::vector<pt_ctx*> ranks;          // ranks[0] = the context the caller holds
     std::vector<float4*> accum;          // private accumulation buffer of each rank (its own pixels, zero elsewhere)
-    size_t accum_pixels = 0;
+    uint32_t accum_w = 0, accum_h = 0;   // image shape the private buffers were allocated for
     bool rehearsal = false;              // all ranks on ONE device (one-GPU box): a sum kernel stands in for RCCL
     RcclApi rccl;
     std::vector<ncclComm_t> comms;
@@ -725,15 +734,22 @@ static int launch_frames_multi(pt_ctx* c, const pt_params* p, uint32_t n_frames)
     if (pixels > 0x7FFFFFFFull / 4u) return fail(c, "pt_launch: image too large for the group reduce");
     // private buffers: (re)allocated zero-filled; a launch that is not the straight continuation of the previous one with
     // frame > 0 (a restored accumulation) first takes the caller's values for the rank's own pixels
-    const bool fresh = m->accum_pixels != pixels;
-    const bool continues = !fresh && p->accumulationBuffer == m->cont_accum && p->currentFrameIdx == m->cont_frame && p->width == m->cont_w && p->height == m->cont_h;
+    // The tile layout depends on the image SHAPE, not on its pixel count (640x360 and 360x640 share one): keyed on (width, height).
+    const bool fresh = m->accum_w != p->width || m->accum_h != p->height;
+    const bool continues = !fresh && p->currentFrameIdx > 0u && p->accumulationBuffer == m->cont_accum && p->currentFrameIdx == m->cont_frame && p->width == m->cont_w && p->height == m->cont_h;
+    if (!continues && p->currentFrameIdx > 0u) {      // the ranks are about to read the caller's buffer: what the caller queued on its stream (pt_set_stream) comes first
+        CK(c, hipSetDevice(c->device));
+        CK(c, hipStreamSynchronize(c->stream));
+    }
     int rc = on_every_rank(c, [&](pt_ctx* r, int i) -> int {
         CK(r, hipSetDevice(r->device));
         if (fresh) {
             if (m->accum[(size_t)i]) { CK(r, hipStreamSynchronize(r->stream)); (void)hipFree(m->accum[(size_t)i]); m->accum[(size_t)i] = nullptr; }
             CK(r, hipMalloc((void**)&m->accum[(size_t)i], pixels * sizeof(float4)));
-            CK(r, hipMemsetAsync(m->accum[(size_t)i], 0, pixels * sizeof(float4), r->stream));
         }
+        // every launch that is not a straight continuation starts from "own pixels or zero": the reduce relies on every pixel
+        // having exactly one non-zero term, whatever an earlier launch of another shape or frame sequence left behind
+        if (!continues) CK(r, hipMemsetAsync(m->accum[(size_t)i], 0, pixels * sizeof(float4), r->stream));
         if (p->currentFrameIdx > 0u && !continues) {
             CK(r, hipMemcpyAsync(m->accum[(size_t)i], p->accumulationBuffer, pixels * sizeof(float4), hipMemcpyDefault, r->stream));
             CK(r, ptd::launch_keep_owned(m->accum[(size_t)i], p->width, p->height, i, world, r->stream));
@@ -745,7 +761,7 @@ static int launch_frames_multi(pt_ctx* c, const pt_params* p, uint32_t n_frames)
         return launch_frames_single(r, &q, n_frames);
     });
     if (rc) return rc;
-    m->accum_pixels = pixels;
+    m->accum_w = p->width; m->accum_h = p->height;
     {
         Range range("acgpt: reduce of the accumulation buffers to rank 0");
         const auto tr = std::chrono::steady_clock::now();
@@ -755,14 +771,18 @@ static int launch_frames_multi(pt_ctx* c, const pt_params* p, uint32_t n_frames)
             CK(c, ptd::launch_sum_ranks((float4*)p->accumulationBuffer, src.data(), world, (uint32_t)pixels, c->stream));
             CK(c, hipStreamSynchronize(c->stream));
         } else {
+            // no early return between GroupStart and GroupEnd: an open group would leave the communicators unusable
             ncclResult_t r = m->rccl.GroupStart();
-            for (int i = 0; i < world && r == ncclSuccess; i++) {
-                CK(c, hipSetDevice(m->ranks[(size_t)i]->device));
+            hipError_t dev_err = hipSuccess;
+            for (int i = 0; i < world && r == ncclSuccess && dev_err == hipSuccess; i++) {
+                dev_err = hipSetDevice(m->ranks[(size_t)i]->device);
+                if (dev_err != hipSuccess) break;
                 r = m->rccl.Reduce(m->accum[(size_t)i], i == 0 ? (void*)p->accumulationBuffer : (void*)m->accum[(size_t)i], pixels * 4u, ncclFloat, ncclSum, 0,
                                    m->comms[(size_t)i], m->ranks[(size_t)i]->stream);
             }
             const ncclResult_t e = m->rccl.GroupEnd();
             if (r == ncclSuccess) r = e;
+            if (dev_err != hipSuccess) return fail(c, std::string("pt_launch: hipSetDevice before ncclReduce: ") + hipGetErrorString(dev_err));
             if (r != ncclSuccess) return fail(c, std::string("pt_launch: ncclReduce: ") + m->rccl.GetErrorString(r));
             for (int i = world - 1; i >= 0; i--) { CK(c, hipSetDevice(m->ranks[(size_t)i]->device)); CK(c, hipStreamSynchronize(m->ranks[(size_t)i]->stream)); }
         }

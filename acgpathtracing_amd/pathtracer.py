@@ -383,6 +383,8 @@ def saveAccumulation(state, filename):
 
 def restoreAccumulation(state, filename):
     """Continue a saved run: fills params.accumulationBuffer and sets currentFrameIdx to the frames accumulated so far."""
+    if state.refreshAccumulationBuffer:      # a pending reset (setMathMode, setLightMode, a key toggle) would discard what is restored here
+        updateState(None, state)
     h, w = int(state.params.height), int(state.params.width)
     with open(filename, "rb") as fh:
         blob = fh.read()

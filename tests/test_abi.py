@@ -124,3 +124,22 @@ def test_variant_kernel_names_are_the_code_objects(lib):
     assert n >= 10
     assert re.fullmatch(r"[0-9a-f]{16}", lib.pt_kernel_source_hash().decode())
     assert lib.pt_kernel_source_hash().decode() == _build.kernel_source_hash()
+
+
+def test_load_order_rule_is_enforced_not_only_documented():
+    """torch's GPU runtime must be up before libacgpt_hip.so is loaded.  _native.hip() sees to it
+    (default), leaves torch alone on request, or refuses with the reason — in fresh processes, where nothing is loaded yet."""
+    import sys
+    code = "import sys; from acgpathtracing_amd import _native; assert 'torch' not in sys.modules; _native.hip(); print('torch' in sys.modules)"
+    def run(mode):
+        env = dict(os.environ)
+        env.pop("ACGPT_TORCH_FIRST", None)
+        if mode is not None:
+            env["ACGPT_TORCH_FIRST"] = mode
+        return subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    r = run(None)
+    assert r.returncode == 0 and r.stdout.strip() == "True", r.stderr[-2000:]
+    r = run("0")
+    assert r.returncode == 0 and r.stdout.strip() == "False", r.stderr[-2000:]
+    r = run("error")
+    assert r.returncode != 0 and "INTEGRATION.md section 5" in r.stderr and "ACGPT_TORCH_FIRST=0" in r.stderr

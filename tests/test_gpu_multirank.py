@@ -121,3 +121,84 @@ def test_group_context_behind_the_c_abi(built, tmp_path):
         rest = _app(tmp_path, tag + "b", extra + ["--restore-accum", str(tmp_path / (tag + "a.acc"))], env, frames=2)
         assert "Accumulation restored: 3 frames" in rest[2]
         assert first[1] != one[1] and rest[:2] == one[:2], tag
+
+
+def _render_frames(state, frames, fuse=1):
+    import ctypes as C
+    import acgpathtracing_amd as pt
+    for f in range(0, frames, fuse):
+        pt.updateState(None, state)
+        pt.LaunchCurrentFrame(None, state, sub_frames=min(fuse, frames - f))
+        state.params.currentFrameIdx += min(fuse, frames - f)
+    return pt.readAccumulation(state)
+
+
+def test_group_context_reshaped_with_the_same_pixel_count(built):
+    """a group context that goes from W x H to H x W (same pixel count, another tile layout) must not keep the old
+    layout's pixels in its ranks' private buffers; and a restart at frame 0 on the same buffer starts from zero."""
+    import ctypes as C
+    import acgpathtracing_amd as pt
+    from acgpathtracing_amd import _native
+    L = _native.hip()
+    obj_path = os.path.join(pt.SCENES, "cornell_box.obj")
+    assert "ACGPT_REHEARSE_SAME_GPU" not in os.environ
+    os.environ["ACGPT_REHEARSE_SAME_GPU"] = "1"
+    try:
+        grp, _ = pt.setup(obj_path, width=96, height=64, max_depth=4, direct_lighting=True, importance_sampling=True, spp=8, device_ids=[0, 0, 0])
+    finally:
+        del os.environ["ACGPT_REHEARSE_SAME_GPU"]
+    one, _ = pt.setup(obj_path, width=96, height=64, max_depth=4, direct_lighting=True, importance_sampling=True, spp=8)
+    try:
+        assert L.pt_device_count(grp.context) == 3
+        for st in (grp, one):
+            assert L.pt_set_sample_chunks(st.context, 4) == 0
+        want = _render_frames(one, 3)
+        got = _render_frames(grp, 3)
+        assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
+        # the same contexts, the transposed shape: 64 x 96 has the pixel count of 96 x 64 and another tile layout
+        for st in (grp, one):
+            cam = pt.initCamera(); cam.setAspectRatio(np.float32(64) / np.float32(96))
+            U, V, W = cam.UVWFrame()
+            st.params.width, st.params.height = 64, 96
+            st.params.cameraU, st.params.cameraV, st.params.cameraW = pt.pathtracer._f3(U), pt.pathtracer._f3(V), pt.pathtracer._f3(W)
+            st.refreshAccumulationBuffer = True
+        want = _render_frames(one, 3)
+        got = _render_frames(grp, 3)
+        assert want.shape == (96, 64, 4) and np.array_equal(want.view(np.uint32), got.view(np.uint32)), "stale pixels of the old tile layout in the reduce"
+        # restart at frame 0 into the SAME caller buffer (no reallocation): nothing of the previous sequence may survive
+        for st in (grp, one):
+            st.params.currentFrameIdx = 0
+        want = _render_frames(one, 2)
+        got = _render_frames(grp, 2)
+        assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
+    finally:
+        pt.CleanAllTheThings(grp); pt.CleanAllTheThings(one)
+
+
+def test_python_save_restore_with_a_pending_refresh(built, tmp_path):
+    """restoreAccumulation after setup(math_mode=...) — whose refresh flag is still pending — must not be discarded
+    by the next updateState: 3 frames, save, new state, restore, 2 frames == 5 frames straight."""
+    import acgpathtracing_amd as pt
+    obj_path = os.path.join(pt.SCENES, "cornell_box.obj")
+    kw = dict(width=80, height=48, max_depth=5, direct_lighting=True, importance_sampling=True, spp=8, math_mode="ieee")
+    a, _ = pt.setup(obj_path, **kw)
+    try:
+        straight = _render_frames(a, 5)
+    finally:
+        pt.CleanAllTheThings(a)
+    b, _ = pt.setup(obj_path, **kw)
+    try:
+        _render_frames(b, 3)
+        dump = str(tmp_path / "three.acc")
+        pt.saveAccumulation(b, dump)
+    finally:
+        pt.CleanAllTheThings(b)
+    c, _ = pt.setup(obj_path, **kw)
+    try:
+        assert c.refreshAccumulationBuffer          # setMathMode left it pending
+        pt.restoreAccumulation(c, dump)
+        assert int(c.params.currentFrameIdx) == 3 and not c.refreshAccumulationBuffer
+        rest = _render_frames(c, 2)
+    finally:
+        pt.CleanAllTheThings(c)
+    assert np.array_equal(straight.view(np.uint32), rest.view(np.uint32))
