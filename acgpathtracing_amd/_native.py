@@ -56,14 +56,15 @@ class BvhInfo(C.Structure):
                 ("scene_lo", C.c_float * 3), ("scene_hi", C.c_float * 3), ("build_ms", C.c_float),
                 ("node_bytes", C.c_uint32), ("tri_bytes", C.c_uint32),
                 ("wide_nodes", C.c_uint32), ("wide_depth", C.c_uint32), ("wide_bytes", C.c_uint32), ("wide_ms", C.c_float),
-                ("half_node_bytes", C.c_uint32), ("half_area_ratio", C.c_float), ("half_box_inflation", C.c_float)]
+                ("half_node_bytes", C.c_uint32), ("half_area_ratio", C.c_float), ("half_box_inflation", C.c_float),
+                ("device_bytes", C.c_uint64)]
 
 
 assert C.sizeof(PathTraceParams) == 168
 assert C.sizeof(Material) == 40
 assert C.sizeof(AreaLight) == 60
-assert C.sizeof(Stats) == 96 and C.sizeof(BvhInfo) == 80          # ABI version 3 (include/acgpt.h)
-ABI_VERSION = 3
+assert C.sizeof(Stats) == 96 and C.sizeof(BvhInfo) == 88          # ABI version 4 (include/acgpt.h)
+ABI_VERSION = 4
 MATH_IEEE, MATH_FAST = 0, 1                                        # pt_set_math_mode
 
 # every symbol include/acgpt.h declares (the drop-in boundary) ...

@@ -36,7 +36,7 @@ typedef enum { ncclSum = 0 } ncclRedOp_t;
 static_assert(sizeof(pt_params) == 168, "pt_params must mirror PathTraceParams (168 bytes)");
 static_assert(sizeof(pt_material) == 40, "pt_material must mirror Material (40 bytes)");
 static_assert(sizeof(pt_area_light) == 60, "pt_area_light must mirror AreaLight (60 bytes)");
-static_assert(sizeof(pt_stats) == 96 && sizeof(pt_bvh_info) == 80, "ABI version 3: a change of these layouts bumps pt_abi_version");
+static_assert(sizeof(pt_stats) == 96 && sizeof(pt_bvh_info) == 88, "ABI version 4: a change of these layouts bumps pt_abi_version");
 
 struct pt_multi;
 
@@ -145,7 +145,7 @@ struct pt_multi {
     pt_stats group_stats;
 };
 
-PT_API uint32_t pt_abi_version(void) { return 3u; }
+PT_API uint32_t pt_abi_version(void) { return 4u; }
 
 PT_API const char* pt_last_error(pt_ctx* ctx)
 {
@@ -338,6 +338,7 @@ static int ensure_top(pt_ctx* c)
 {
     if (ptd::render_variant_top_nodes(c->variant) == 0) return 0;
     std::string err;
+    if (!ptd::ensure_hnodes(c->bvh, c->stream, err)) return fail(c, err);
     if (!ptd::build_top_nodes(c->bvh, c->stream, err)) return fail(c, err);
     return 0;
 }
@@ -346,8 +347,32 @@ static int ensure_wide(pt_ctx* c)
 {
     if (c->bvh.wrecs || c->bvh.n_tris == 0) return 0;
     std::string err;
+    if (!ptd::ensure_nodes(c->bvh, c->stream, err)) return fail(c, err);
     if (!ptd::build_wide4(c->bvh, c->stream, err)) return fail(c, err);
     return size_stack(c);
+}
+
+// The node array a kernel variant traverses, present on the device before anything is launched on it.  A scene keeps one of
+// the two — set_scene_one releases the other — and any of them comes back on first use (lbvh_build.h).
+static int ensure_node_format(pt_ctx* c, int fmt)
+{
+    if (c->bvh.n_tris == 0) return 0;
+    std::string err;
+    bool ok = true;
+    switch (fmt) {
+        case 0: case 5: ok = ptd::ensure_nodes(c->bvh, c->stream, err); break;
+        case 7: case 8: case 9: ok = ptd::ensure_hnodes(c->bvh, c->stream, err); break;
+        case 1: case 2: case 4: ok = ptd::ensure_qnodes(c->bvh, c->stream, err); break;
+        case 6: ok = ptd::ensure_cnodes(c->bvh, c->stream, err); break;
+        case 3: return ensure_wide(c);
+        default: return fail(c, "unknown node format");
+    }
+    return ok ? 0 : fail(c, err);
+}
+static int ensure_variant_arrays(pt_ctx* c)
+{
+    if (int rc = ensure_node_format(c, ptd::render_variant_node_format(c->variant))) return rc;
+    return ensure_top(c);
 }
 
 static int set_scene_one(pt_ctx* c, const float* verts_xyzw, size_t n_verts, const uint32_t* idx, size_t n_tris,
@@ -413,8 +438,12 @@ static int set_scene_one(pt_ctx* c, const float* verts_xyzw, size_t n_verts, con
     }
     if (int rc = size_stack(c)) return rc;              // stack depth first: the choice below depends on it
     if (c->variant_auto) { c->variant = pick_variant(c); if (int rc = size_stack(c)) return rc; }
-    if (ptd::render_variant_node_format(c->variant) == 3) { if (int rc = ensure_wide(c)) return rc; }
-    if (int rc = ensure_top(c)) return rc;
+    {   // one node array per scene: the one the chosen kernel reads (fp16: 32 B per node, fp32: 64 B); the other comes back on first use
+        const int fmt = ptd::render_variant_node_format(c->variant);
+        if (fmt == 7 || fmt == 8 || fmt == 9) ptd::release_nodes(c->bvh);
+        else if (fmt == 0 || fmt == 5) ptd::release_hnodes(c->bvh);
+    }
+    if (int rc = ensure_variant_arrays(c)) return rc;
     c->scene_serial++;
     return 0;
 }
@@ -440,6 +469,7 @@ PT_API int pt_get_bvh_info(pt_ctx* c, pt_bvh_info* out)
     out->half_node_bytes = c->bvh.n_nodes * (uint32_t)sizeof(ptd::HNode);
     out->half_area_ratio = c->bvh.half_area_ratio;
     out->half_box_inflation = c->bvh.half_box_inflation;
+    out->device_bytes = (uint64_t)ptd::scene_device_bytes(c->bvh);
     return 0;
 }
 
@@ -496,8 +526,7 @@ static int set_tuning_one(pt_ctx* c, int blocks_per_cu, int variant)
     c->tune_blocks_per_cu = blocks_per_cu;
     c->variant_auto = variant < 0;
     c->variant = variant < 0 ? pick_variant(c) : variant;
-    if (ptd::render_variant_node_format(c->variant) == 3) { if (int rc = ensure_wide(c)) return rc; }
-    if (int rc = ensure_top(c)) return rc;
+    if (int rc = ensure_variant_arrays(c)) return rc;
     CK(c, ptd::render_occupancy(c->variant, c->math_mode, c->stack_entries, c->bvh.n_nodes, &c->blocks_per_cu));
     if (c->blocks_per_cu < 1) return fail(c, "pt_set_tuning: this kernel variant does not fit the current scene in LDS");
     return 0;
@@ -846,6 +875,10 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
     if (!p->accumulationBuffer) return fail(c, "pt_launch: accumulationBuffer is null");
     if (p->handle != 0 && p->handle != c->scene_serial) return fail(c, "pt_launch: stale scene handle");
     CK(c, hipSetDevice(c->device));
+    // light mode 1 has its own kernel (the estimator differs); every other choice is c->variant.  The node array that kernel
+    // walks is on the device before the launch (a scene keeps one array; the lights kernel reads the fp16 nodes whatever the scene chose)
+    const int variant = c->light_mode == 1 ? ptd::kVariantLights : c->variant;
+    if (int rc = ensure_node_format(c, ptd::render_variant_node_format(variant))) return rc;
 
     ptd::RenderArgs a;
     memset(&a, 0, sizeof(a));
@@ -962,8 +995,6 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
     a.stack_entries = c->stack_entries;
     a.n_lds_nodes = c->bvh.n_nodes;
 
-    // light mode 1 has its own kernel (the estimator differs); every other choice is c->variant
-    const int variant = c->light_mode == 1 ? ptd::kVariantLights : c->variant;
     int fit = c->blocks_per_cu;
     if (variant != c->variant || fit < 1) {   // (fit < 1: no scene yet — empty world, every ray misses)
         CK(c, ptd::render_occupancy(variant, c->math_mode, c->stack_entries, c->bvh.n_nodes, &fit));
@@ -1080,6 +1111,8 @@ static int trace_common(pt_ctx* c, const float* rays, size_t n, size_t out_bytes
 PT_API int pt_trace_closest(pt_ctx* c, const float* rays, size_t n, float* t_out, uint32_t* prim_out)
 {
     if (!c || (n && (!rays || !t_out || !prim_out))) return fail(c, "pt_trace_closest: null argument");
+    CK(c, hipSetDevice(c->device));
+    if (int rc = ensure_node_format(c, 0)) return rc;          // the query kernels walk the fp32 nodes
     const ptd::DeviceScene sc = device_scene(c);
     const uint32_t se = c->stack_entries;
     hipStream_t s = c->stream;
@@ -1091,6 +1124,8 @@ PT_API int pt_trace_closest(pt_ctx* c, const float* rays, size_t n, float* t_out
 PT_API int pt_trace_any(pt_ctx* c, const float* rays, size_t n, uint8_t* hit_out)
 {
     if (!c || (n && (!rays || !hit_out))) return fail(c, "pt_trace_any: null argument");
+    CK(c, hipSetDevice(c->device));
+    if (int rc = ensure_node_format(c, 0)) return rc;
     const ptd::DeviceScene sc = device_scene(c);
     const uint32_t se = c->stack_entries;
     hipStream_t s = c->stream;
@@ -1104,9 +1139,9 @@ PT_API int pt_bench_traversal(pt_ctx* c, const float* rays, size_t n, int repeat
 {
     if (!c || !rays || !t_out || !prim_out || !ms_out || n == 0 || n > 0x7FFFFFFFull || repeats < 1 || node_format < 0 || node_format > 3)
         return fail(c, "pt_bench_traversal: bad argument");
-    if (node_format == 1) { if (int rc = ensure_wide(c)) return rc; }
-    const uint32_t entries = node_format == 1 ? (c->bvh.wide_depth + 1u) : c->stack_entries;
     CK(c, hipSetDevice(c->device));
+    if (int rc = ensure_node_format(c, node_format == 1 ? 3 : node_format == 3 ? 9 : 0)) return rc;       // stream formats 0 / 2: fp32 nodes, 3: fp16, 1: four-wide
+    const uint32_t entries = node_format == 1 ? (c->bvh.wide_depth + 1u) : c->stack_entries;
     float* d_rays = nullptr; float* d_t = nullptr; uint32_t* d_p = nullptr; uint32_t* d_head = nullptr;
     int bpc = 0;
     hipError_t e = ptd::trace_stream_occupancy(node_format, entries, &bpc);
@@ -1237,8 +1272,8 @@ PT_API int pt_read_morton(pt_ctx* c, uint32_t* codes_sorted, uint32_t* prims_sor
     if (!c || !codes_sorted || !prims_sorted) return fail(c, "pt_read_morton: null argument");
     if (c->bvh.n_tris == 0) return 0;
     CK(c, hipSetDevice(c->device));
-    CK(c, hipMemcpy(codes_sorted, c->bvh.keys_sorted, (size_t)c->bvh.n_tris * 4, hipMemcpyDeviceToHost));
-    CK(c, hipMemcpy(prims_sorted, c->bvh.vals_sorted, (size_t)c->bvh.n_tris * 4, hipMemcpyDeviceToHost));
+    std::string err;
+    if (!ptd::read_morton(c->bvh, c->stream, codes_sorted, prims_sorted, err)) return fail(c, "pt_read_morton: " + err);
     return 0;
 }
 

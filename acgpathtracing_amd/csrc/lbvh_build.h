@@ -9,10 +9,13 @@
 namespace ptd {
 
 struct LbvhResult {
+    // A scene keeps ONE of the two node arrays below — the one its render kernel reads; the other is released after the build
+    // (release_nodes / release_hnodes) and comes back, bit for bit, on first use (ensure_nodes / ensure_hnodes).
     BvhNode*   nodes = nullptr;        // device, n_nodes (fp32 boxes, 64 B)
-    QNode*     qnodes = nullptr;       // device, n_nodes (16-bit grid boxes, 32 B)
-    BvhNode*   cnodes = nullptr;       // device, n_nodes (centre + half-extent boxes, 64 B)
     HNode*     hnodes = nullptr;       // device, n_nodes (fp16 boxes, 32 B)
+    QNode*     qnodes = nullptr;       // device, n_nodes (16-bit grid boxes, 32 B): experiment formats, on first use (ensure_qnodes)
+    BvhNode*   cnodes = nullptr;       // device, n_nodes (centre + half-extent boxes, 64 B): experiment format, on first use (ensure_cnodes)
+    float      pad_abs = 0.0f;         // absolute pad of the triangle boxes (record_aabb): 2^-19 of the scene's largest |coordinate|
     HNode*     top_nodes = nullptr;    // device, kTopNodesMax: the first n_top inner nodes breadth first (children inside the array: kTopNodeFlag | position)
     uint32_t   n_top = 0;
     HSpace     hspace = {0, 0, 0, 1};
@@ -24,8 +27,6 @@ struct LbvhResult {
     uint4*     wrecs = nullptr;        // device, n_wrecs x 48 B: four-wide nodes + triangles (wide_bvh.hip)
     uint32_t   n_wrecs = 0, n_wnodes = 0, wide_depth = 0;
     float      wide_ms = 0.0f;         // host collapse + upload
-    uint32_t*  keys_sorted = nullptr;  // device, n_tris
-    uint32_t*  vals_sorted = nullptr;  // device, n_tris (original triangle index per slot)
     uint32_t   n_tris = 0, n_nodes = 0, max_depth = 0;
     float      scene_lo[3] = {0, 0, 0}, scene_hi[3] = {0, 0, 0};
     float      build_ms = 0.0f;
@@ -39,6 +40,20 @@ bool build_lbvh(const float* h_verts_xyzw, size_t n_verts, const uint32_t* h_idx
                 const uint32_t* h_mat_ids, int mode, hipStream_t stream, LbvhResult& out, std::string& err);
 
 void free_lbvh(LbvhResult& r);
+
+// One node array per scene: release the one the chosen kernel does not read (no-op when it is the only copy of the topology) ...
+void release_nodes(LbvhResult& r);       // frees the fp32 nodes and the experiment formats derived from them
+void release_hnodes(LbvhResult& r);      // frees the fp16 nodes (and the staged top of the tree)
+// ... and get any of them back on first use.  fp32 nodes: from the topology in the fp16 nodes + the triangle records, the same bits as
+// the build's own (unions are exact); the others from the fp32 nodes.  Synchronous on return.
+bool ensure_nodes(LbvhResult& r, hipStream_t stream, std::string& err);
+bool ensure_hnodes(LbvhResult& r, hipStream_t stream, std::string& err);
+bool ensure_qnodes(LbvhResult& r, hipStream_t stream, std::string& err);
+bool ensure_cnodes(LbvhResult& r, hipStream_t stream, std::string& err);
+// (Morton code, original triangle index) per leaf slot in sorted order, recomputed from the records (the build keeps no copy of its sort keys)
+bool read_morton(const LbvhResult& r, hipStream_t stream, uint32_t* h_codes, uint32_t* h_prims, std::string& err);
+// bytes of device memory the scene's arrays hold right now
+size_t scene_device_bytes(const LbvhResult& r);
 
 // Writes each material's bsdfType and whether it emits into the upper byte of the shade records' material word (pt_device.h
 // kShadeBsdfShift, kShadeHasKe), once the repacked materials are on the device: what lets closest-hit shading fetch

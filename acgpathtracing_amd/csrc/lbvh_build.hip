@@ -35,6 +35,24 @@ __host__ __device__ inline float ord2f(uint32_t u)
 }
 
 // --- 1. triangle records + bounds -------------------------------------------------
+// Padded AABB of a triangle FROM ITS RECORD (v0, e1, e2): the corners are v0, v0 + e1, v0 + e2 — the triangle the
+// Moeller-Trumbore test works on — so that the boxes can be recomputed from the records alone, bit for bit, after the fp32
+// node array has been released (refit_nodes below).  pad: the triangle test accepts rays a few ulps outside the exact triangle
+// (relative term), and the render kernel's slab test t = p * (1/d) - o/d rounds -o/d once, i.e. moves a plane by up to
+// |o| * 2^-24; pad_abs = 2^-19 of the largest |coordinate| of the scene covers that for ray origins up to 32 scene sizes away.
+__device__ __forceinline__ void record_aabb(const TriRecord& r, float pad_abs, float lo[3], float hi[3])
+{
+    const float pa[3] = {r.r0.x, r.r0.y, r.r0.z};
+    const float pb[3] = {pa[0] + r.r0.w, pa[1] + r.r1.x, pa[2] + r.r1.y};
+    const float pc[3] = {pa[0] + r.r1.z, pa[1] + r.r1.w, pa[2] + r.r2.x};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float l = fminf(pa[k], fminf(pb[k], pc[k])), h = fmaxf(pa[k], fmaxf(pb[k], pc[k]));
+        const float pad = fmaxf(1e-5f * fmaxf(1.0f, fmaxf(fabsf(l), fabsf(h))), pad_abs);
+        lo[k] = l - pad; hi[k] = h + pad;
+    }
+}
+
 __global__ void k_prepare(const float4* __restrict__ verts, const uint32_t* __restrict__ idx,
                           const uint32_t* __restrict__ mat_ids, uint32_t n_tris,
                           TriRecord* __restrict__ tri_unsorted, float4* __restrict__ tri_lo, float4* __restrict__ tri_hi,
@@ -49,16 +67,7 @@ __global__ void k_prepare(const float4* __restrict__ verts, const uint32_t* __re
         r.r1 = make_float4(b.y - a.y, b.z - a.z, c.x - a.x, c.y - a.y);
         r.r2 = make_float4(c.z - a.z, __uint_as_float(i), __uint_as_float(mat_ids[i]), 0.0f);
         tri_unsorted[i] = r;
-        const float pa[3] = {a.x, a.y, a.z}, pb[3] = {b.x, b.y, b.z}, pc[3] = {c.x, c.y, c.z};
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            float l = fminf(pa[k], fminf(pb[k], pc[k])), h = fmaxf(pa[k], fmaxf(pb[k], pc[k]));
-            // pad: the triangle test accepts rays a few ulps outside the exact triangle (relative term), and the render
-            // kernel's slab test t = p * (1/d) - o/d rounds -o/d once, i.e. moves a plane by up to |o| * 2^-24; pad_abs =
-            // 2^-19 of the largest |coordinate| of the scene covers that for ray origins up to 32 scene sizes away
-            float pad = fmaxf(1e-5f * fmaxf(1.0f, fmaxf(fabsf(l), fabsf(h))), pad_abs);
-            lo[k] = l - pad; hi[k] = h + pad;
-        }
+        record_aabb(r, pad_abs, lo, hi);
         tri_lo[i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
         tri_hi[i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
     }
@@ -88,15 +97,9 @@ __device__ __forceinline__ uint32_t expand10(uint32_t v)
     v = (v * 0x00000005u) & 0x49249249u;
     return v;
 }
-__global__ void k_morton(const float4* __restrict__ tri_lo, const float4* __restrict__ tri_hi, uint32_t n_tris,
-                         const uint32_t* __restrict__ scene_bounds, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+__device__ __forceinline__ uint32_t morton30(const float l[3], const float h[3], const float slo[3], const float shi[3])
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_tris) return;
-    const float slo[3] = {ord2f(scene_bounds[0]), ord2f(scene_bounds[1]), ord2f(scene_bounds[2])};
-    const float shi[3] = {ord2f(scene_bounds[3]), ord2f(scene_bounds[4]), ord2f(scene_bounds[5])};
-    const float4 l = tri_lo[i], h = tri_hi[i];
-    const float c[3] = {0.5f * (l.x + h.x), 0.5f * (l.y + h.y), 0.5f * (l.z + h.z)};
+    const float c[3] = {0.5f * (l[0] + h[0]), 0.5f * (l[1] + h[1]), 0.5f * (l[2] + h[2])};
     uint32_t q[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -105,8 +108,33 @@ __global__ void k_morton(const float4* __restrict__ tri_lo, const float4* __rest
         u = fminf(fmaxf(u * 1024.0f, 0.0f), 1023.0f);
         q[k] = (uint32_t)u;
     }
-    keys[i] = (expand10(q[0]) << 2) | (expand10(q[1]) << 1) | expand10(q[2]);
+    return (expand10(q[0]) << 2) | (expand10(q[1]) << 1) | expand10(q[2]);
+}
+__global__ void k_morton(const float4* __restrict__ tri_lo, const float4* __restrict__ tri_hi, uint32_t n_tris,
+                         const uint32_t* __restrict__ scene_bounds, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tris) return;
+    const float slo[3] = {ord2f(scene_bounds[0]), ord2f(scene_bounds[1]), ord2f(scene_bounds[2])};
+    const float shi[3] = {ord2f(scene_bounds[3]), ord2f(scene_bounds[4]), ord2f(scene_bounds[5])};
+    const float4 l4 = tri_lo[i], h4 = tri_hi[i];
+    const float l[3] = {l4.x, l4.y, l4.z}, h[3] = {h4.x, h4.y, h4.z};
+    keys[i] = morton30(l, h, slo, shi);
     vals[i] = i;
+}
+// the (code, triangle) pairs of the sorted order, recomputed from the records (pt_read_morton: the build keeps no copy of its keys)
+struct Bounds6 { float v[6]; };      // lo xyz, hi xyz
+__global__ void k_morton_of_records(const TriRecord* __restrict__ tris, uint32_t n_tris, float pad_abs, const Bounds6 bounds,
+                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ prims)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tris) return;
+    const TriRecord r = tris[i];
+    float l[3], h[3];
+    record_aabb(r, pad_abs, l, h);
+    const float slo[3] = {bounds.v[0], bounds.v[1], bounds.v[2]}, shi[3] = {bounds.v[3], bounds.v[4], bounds.v[5]};
+    keys[i] = morton30(l, h, slo, shi);
+    prims[i] = __float_as_uint(r.r2.y);
 }
 
 // --- 3. LSD radix sort, 8 bits per pass ---------------------------------------------
@@ -249,12 +277,6 @@ __host__ __device__ inline QGrid make_qgrid_f(const float lo[3], const float hi[
     g.icx = 1.0f / c[0]; g.icy = 1.0f / c[1]; g.icz = 1.0f / c[2];
     return g;
 }
-__device__ __forceinline__ QGrid make_qgrid(const uint32_t* __restrict__ scene_bounds)
-{
-    const float lo[3] = {ord2f(scene_bounds[0]), ord2f(scene_bounds[1]), ord2f(scene_bounds[2])};
-    const float hi[3] = {ord2f(scene_bounds[3]), ord2f(scene_bounds[4]), ord2f(scene_bounds[5])};
-    return make_qgrid_f(lo, hi);
-}
 // outward rounding plus one cell of slack on each side: the slack absorbs the rounding of the
 // ray's own world->grid transform (a few 1e-3 cells), see DESIGN.md
 __device__ __forceinline__ uint32_t q_lo(float w, float o, float ic)
@@ -297,7 +319,7 @@ __global__ void k_gather_leaves(const uint32_t* __restrict__ vals_sorted, uint32
 __global__ void k_refit(int n, const uint32_t* __restrict__ vals_sorted, const float4* __restrict__ tri_lo, const float4* __restrict__ tri_hi,
                         const int2* __restrict__ children, const int* __restrict__ node_parent, const int* __restrict__ leaf_parent,
                         uint32_t* __restrict__ visit, float4* __restrict__ node_lo, float4* __restrict__ node_hi /* .w = height */,
-                        BvhNode* __restrict__ nodes, QNode* __restrict__ qnodes, const uint32_t* __restrict__ scene_bounds)
+                        BvhNode* __restrict__ nodes)
 {
     const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
     if (leaf >= n) return;
@@ -318,7 +340,6 @@ __global__ void k_refit(int n, const uint32_t* __restrict__ vals_sorted, const f
         nd.c = make_float4(l1.z, h1.x, h1.y, h1.z);
         nd.d = make_int4(ch.x, ch.y, 0, 0);
         nodes[cur] = nd;
-        qnodes[cur] = quantise_node(make_qgrid(scene_bounds), l0, h0, l1, h1, ch.x, ch.y);
         node_lo[cur] = make_float4(fminf(l0.x, l1.x), fminf(l0.y, l1.y), fminf(l0.z, l1.z), 0.0f);
         node_hi[cur] = make_float4(fmaxf(h0.x, h1.x), fmaxf(h0.y, h1.y), fmaxf(h0.z, h1.z), 1.0f + fmaxf(hgt0, hgt1));
         cur = node_parent[cur];
@@ -327,7 +348,7 @@ __global__ void k_refit(int n, const uint32_t* __restrict__ vals_sorted, const f
 
 // Single-triangle scene: one node whose second child is an empty box.
 __global__ void k_single_node(const float4* __restrict__ tri_lo, const float4* __restrict__ tri_hi, BvhNode* __restrict__ nodes,
-                              float4* __restrict__ node_hi, QNode* __restrict__ qnodes, const uint32_t* __restrict__ scene_bounds)
+                              float4* __restrict__ node_hi)
 {
     const float4 l = tri_lo[0], h = tri_hi[0];
     BvhNode nd;
@@ -336,8 +357,6 @@ __global__ void k_single_node(const float4* __restrict__ tri_lo, const float4* _
     nd.c = make_float4(INFINITY, -INFINITY, -INFINITY, -INFINITY);
     nd.d = make_int4(~0, ~0, 0, 0);
     nodes[0] = nd;
-    qnodes[0] = quantise_node(make_qgrid(scene_bounds), l, h, make_float4(INFINITY, INFINITY, INFINITY, 0.0f),
-                              make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f), ~0, ~0);
     node_hi[0] = make_float4(h.x, h.y, h.z, 1.0f);
 }
 
@@ -436,7 +455,7 @@ __global__ void __launch_bounds__(1024) k_ploc_scan(uint32_t* __restrict__ keep,
 
 __global__ void k_ploc_merge(const Cluster* __restrict__ cin, const uint32_t* __restrict__ nn, const PlocState* __restrict__ st,
                              const uint32_t* __restrict__ keep_pos, const uint32_t* __restrict__ made_pos,
-                             Cluster* __restrict__ cout, BvhNode* __restrict__ nodes, QNode* __restrict__ qnodes, const uint32_t* __restrict__ scene_bounds)
+                             Cluster* __restrict__ cout, BvhNode* __restrict__ nodes)
 {
     const uint32_t m = st->m;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -457,7 +476,6 @@ __global__ void k_ploc_merge(const Cluster* __restrict__ cin, const uint32_t* __
         nd.c = make_float4(other.lo.z, other.hi.x, other.hi.y, other.hi.z);
         nd.d = make_int4(c0, c1, 0, 0);
         nodes[node] = nd;
-        qnodes[node] = quantise_node(make_qgrid(scene_bounds), me.lo, me.hi, other.lo, other.hi, c0, c1);
         Cluster u;
         u.lo = make_float4(fminf(me.lo.x, other.lo.x), fminf(me.lo.y, other.lo.y), fminf(me.lo.z, other.lo.z), __int_as_float((int)node));
         u.hi = make_float4(fmaxf(me.hi.x, other.hi.x), fmaxf(me.hi.y, other.hi.y), fmaxf(me.hi.z, other.hi.z), 1.0f + fmaxf(me.hi.w, other.hi.w));
@@ -475,6 +493,17 @@ __global__ void k_ploc_advance(PlocState* __restrict__ st)
     st->rounds += 1u;
 }
 
+
+// --- 6b. 16-bit grid copy of the nodes (experiment formats 1 / 2 / 4; built on first use from the fp32 nodes) -------------
+__global__ void k_quant_nodes(const BvhNode* __restrict__ nodes, uint32_t n, const QGrid g, QNode* __restrict__ qn)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const BvhNode nd = nodes[i];
+    // child 0: lo (a.x a.y a.z) hi (a.w b.x b.y); child 1: lo (b.z b.w c.x) hi (c.y c.z c.w)
+    qn[i] = quantise_node(g, make_float4(nd.a.x, nd.a.y, nd.a.z, 0.0f), make_float4(nd.a.w, nd.b.x, nd.b.y, 0.0f),
+                          make_float4(nd.b.z, nd.b.w, nd.c.x, 0.0f), make_float4(nd.c.y, nd.c.z, nd.c.w, 0.0f), nd.d.x, nd.d.y);
+}
 
 // --- 7. centre / half-extent copy of the nodes ------------------------------------------------------
 // Slab planes from a centre c and a half extent h need no per-axis min / max (half-rate instructions):
@@ -565,6 +594,61 @@ __global__ void k_top_nodes(const HNode* __restrict__ hn, HNode* __restrict__ to
     *n_out = count;
 }
 
+// --- 10. the fp32 nodes again, from what a scene keeps -----------------------------------------------------------------------
+// A scene whose kernel reads the fp16 nodes does not keep the 64-byte fp32 nodes on the device (they are twice the size of
+// what is traversed).  Whoever needs them later (the ray queries of the parity tests, a switch to an fp32 kernel variant, the
+// experiment formats derived from them) gets them back from the topology in the fp16 nodes and the triangle records: leaf boxes by
+// record_aabb — the very function the build used — and unions bottom-up, which are exact and order-independent: the same bits
+// as the build's own array.
+__global__ void k_parents_of(const HNode* __restrict__ hn, uint32_t n_nodes, int* __restrict__ node_parent, int* __restrict__ leaf_parent)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const int c0 = (int)hn[i].a.w, c1 = (int)hn[i].b.w;
+    if (c0 >= 0) node_parent[c0] = (int)i; else leaf_parent[~c0] = (int)i;
+    if (c1 >= 0) node_parent[c1] = (int)i; else leaf_parent[~c1] = (int)i;
+    if (i == 0u) node_parent[0] = -1;
+}
+__global__ void k_refit_records(int n, const TriRecord* __restrict__ tris, float pad_abs, const HNode* __restrict__ hn,
+                                const int* __restrict__ node_parent, const int* __restrict__ leaf_parent, uint32_t* __restrict__ visit,
+                                float4* __restrict__ node_lo, float4* __restrict__ node_hi, BvhNode* __restrict__ nodes)
+{
+    const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (leaf >= n) return;
+    int cur = leaf_parent[leaf];
+    while (cur >= 0) {
+        const uint32_t prev = __hip_atomic_fetch_add(&visit[cur], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);      // as k_refit: the second arrival proceeds
+        if (prev == 0) return;
+        const int c0 = (int)hn[cur].a.w, c1 = (int)hn[cur].b.w;
+        float l0[3], h0[3], l1[3], h1[3];
+        if (c0 < 0) record_aabb(tris[~c0], pad_abs, l0, h0);
+        else { const float4 a = node_lo[c0], b = node_hi[c0]; l0[0] = a.x; l0[1] = a.y; l0[2] = a.z; h0[0] = b.x; h0[1] = b.y; h0[2] = b.z; }
+        if (c1 < 0) record_aabb(tris[~c1], pad_abs, l1, h1);
+        else { const float4 a = node_lo[c1], b = node_hi[c1]; l1[0] = a.x; l1[1] = a.y; l1[2] = a.z; h1[0] = b.x; h1[1] = b.y; h1[2] = b.z; }
+        BvhNode nd;
+        nd.a = make_float4(l0[0], l0[1], l0[2], h0[0]);
+        nd.b = make_float4(h0[1], h0[2], l1[0], l1[1]);
+        nd.c = make_float4(l1[2], h1[0], h1[1], h1[2]);
+        nd.d = make_int4(c0, c1, 0, 0);
+        nodes[cur] = nd;
+        node_lo[cur] = make_float4(fminf(l0[0], l1[0]), fminf(l0[1], l1[1]), fminf(l0[2], l1[2]), 0.0f);
+        node_hi[cur] = make_float4(fmaxf(h0[0], h1[0]), fmaxf(h0[1], h1[1]), fmaxf(h0[2], h1[2]), 0.0f);
+        cur = node_parent[cur];
+    }
+}
+// single-triangle scene: k_single_node's node from the record
+__global__ void k_single_node_record(const TriRecord* __restrict__ tris, float pad_abs, BvhNode* __restrict__ nodes)
+{
+    float l[3], h[3];
+    record_aabb(tris[0], pad_abs, l, h);
+    BvhNode nd;
+    nd.a = make_float4(l[0], l[1], l[2], h[0]);
+    nd.b = make_float4(h[1], h[2], INFINITY, INFINITY);
+    nd.c = make_float4(INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    nd.d = make_int4(~0, ~0, 0, 0);
+    nodes[0] = nd;
+}
+
 #define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); return false; } } while (0)
 
 namespace {
@@ -597,8 +681,6 @@ void free_lbvh(LbvhResult& r)
     if (r.tris) (void)hipFree(r.tris);
     if (r.shade) (void)hipFree(r.shade);
     if (r.wrecs) (void)hipFree(r.wrecs);
-    if (r.keys_sorted) (void)hipFree(r.keys_sorted);
-    if (r.vals_sorted) (void)hipFree(r.vals_sorted);
     r = LbvhResult();
 }
 
@@ -637,14 +719,14 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
     HIPCK(sc.alloc(&d_children, (size_t)n_nodes * 8));
     HIPCK(sc.alloc(&d_nparent, (size_t)n_nodes * 4));
     HIPCK(sc.alloc(&d_lparent, (size_t)n * 4));
+    // what a scene keeps: the fp32 nodes (the build's own output), their fp16 copy, the triangle and shading records.  The caller
+    // releases the node array its kernel does not read (release_nodes / release_hnodes); either comes back on first use
+    // (ensure_nodes / ensure_hnodes), and so do the experiment formats (ensure_qnodes, ensure_cnodes).
     HIPCK(hipMalloc((void**)&out.nodes, (size_t)n_nodes * sizeof(BvhNode)));
-    HIPCK(hipMalloc((void**)&out.qnodes, (size_t)n_nodes * sizeof(QNode)));
-    HIPCK(hipMalloc((void**)&out.cnodes, (size_t)n_nodes * sizeof(BvhNode)));
     HIPCK(hipMalloc((void**)&out.hnodes, (size_t)n_nodes * sizeof(HNode)));
     HIPCK(hipMalloc((void**)&out.tris, (size_t)n * sizeof(TriRecord)));
     HIPCK(hipMalloc((void**)&out.shade, (size_t)n * sizeof(float4)));
-    HIPCK(hipMalloc((void**)&out.keys_sorted, (size_t)n * 4));
-    HIPCK(hipMalloc((void**)&out.vals_sorted, (size_t)n * 4));
+    out.pad_abs = pad_abs;
 
     HIPCK(hipMemcpyAsync(d_verts, h_verts_xyzw, n_verts * 16, hipMemcpyHostToDevice, stream));
     HIPCK(hipMemcpyAsync(d_idx, h_idx, (size_t)n * 12, hipMemcpyHostToDevice, stream));
@@ -665,8 +747,6 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
                                                              d_keys[cur ^ 1], d_vals[cur ^ 1]);
         cur ^= 1;
     }
-    HIPCK(hipMemcpyAsync(out.keys_sorted, d_keys[cur], (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
-    HIPCK(hipMemcpyAsync(out.vals_sorted, d_vals[cur], (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
     k_gather_leaves<<<blocks, 256, 0, stream>>>(d_vals[cur], n, d_unsorted, out.tris, out.shade);
     if (n > 1 && mode == 1) {
         // PLOC over the sorted order; the cluster arrays ping-pong, flags/positions reuse scratch
@@ -691,7 +771,7 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
                 k_ploc_nn<<<mb, 256, 0, stream>>>(d_c[pc], d_st, d_nn);
                 k_ploc_flags<<<mb, 256, 0, stream>>>(d_nn, d_st, d_keep, d_made);
                 k_ploc_scan<<<1, 1024, 0, stream>>>(d_keep, d_made, d_st);
-                k_ploc_merge<<<mb, 256, 0, stream>>>(d_c[pc], d_nn, d_st, d_keep, d_made, d_c[pc ^ 1], out.nodes, out.qnodes, d_bounds);
+                k_ploc_merge<<<mb, 256, 0, stream>>>(d_c[pc], d_nn, d_st, d_keep, d_made, d_c[pc ^ 1], out.nodes);
                 k_ploc_advance<<<1, 1, 0, stream>>>(d_st);
                 pc ^= 1;
             }
@@ -706,11 +786,10 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
     } else if (n > 1) {
         k_hierarchy<<<(n - 1 + 255) / 256, 256, 0, stream>>>(d_keys[cur], (int)n, d_children, d_nparent, d_lparent);
         k_refit<<<blocks, 256, 0, stream>>>((int)n, d_vals[cur], d_tlo, d_thi, d_children, d_nparent, d_lparent, d_visit,
-                                            d_nlo, d_nhi, out.nodes, out.qnodes, d_bounds);
+                                            d_nlo, d_nhi, out.nodes);
     } else {
-        k_single_node<<<1, 1, 0, stream>>>(d_tlo, d_thi, out.nodes, d_nhi, out.qnodes, d_bounds);
+        k_single_node<<<1, 1, 0, stream>>>(d_tlo, d_thi, out.nodes, d_nhi);
     }
-    k_centre_nodes<<<(n_nodes + 255) / 256, 256, 0, stream>>>(out.nodes, n_nodes, out.cnodes);
     HIPCK(hipGetLastError());
     HIPCK(hipEventRecord(sc.ev1, stream));
     HIPCK(hipMemcpyAsync(h_bounds, d_bounds, 24, hipMemcpyDeviceToHost, stream));
@@ -784,6 +863,117 @@ bool build_top_nodes(LbvhResult& r, hipStream_t stream, std::string& err)
     (void)hipFree(d_ntop);
     if (e != hipSuccess) { err = std::string("top nodes: ") + hipGetErrorString(e); return false; }
     return true;
+}
+
+// ---- node arrays on demand ------------------------------------------------------------------------------------------------
+static bool sync_ok(hipStream_t stream, const char* what, std::string& err)
+{
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) { err = std::string(what) + ": " + hipGetErrorString(e); return false; }
+    return true;
+}
+
+void release_nodes(LbvhResult& r)
+{
+    if (!r.hnodes) return;                  // the only copy of the topology: stays
+    if (r.nodes) { (void)hipFree(r.nodes); r.nodes = nullptr; }
+    if (r.qnodes) { (void)hipFree(r.qnodes); r.qnodes = nullptr; }
+    if (r.cnodes) { (void)hipFree(r.cnodes); r.cnodes = nullptr; }
+}
+
+void release_hnodes(LbvhResult& r)
+{
+    if (!r.nodes) return;
+    if (r.hnodes) { (void)hipFree(r.hnodes); r.hnodes = nullptr; }
+    if (r.top_nodes) { (void)hipFree(r.top_nodes); r.top_nodes = nullptr; r.n_top = 0; }
+}
+
+bool ensure_nodes(LbvhResult& r, hipStream_t stream, std::string& err)
+{
+    if (r.nodes || r.n_tris == 0) return true;
+    if (!r.hnodes || !r.tris) { err = "fp32 nodes: neither node array is present"; return false; }
+    Scratch sc;
+    const uint32_t n = r.n_tris, n_nodes = r.n_nodes;
+    HIPCK(hipMalloc((void**)&r.nodes, (size_t)n_nodes * sizeof(BvhNode)));
+    if (n == 1) {
+        k_single_node_record<<<1, 1, 0, stream>>>(r.tris, r.pad_abs, r.nodes);
+    } else {
+        int *d_np, *d_lp; uint32_t* d_visit; float4 *d_lo, *d_hi;
+        HIPCK(sc.alloc(&d_np, (size_t)n_nodes * 4));
+        HIPCK(sc.alloc(&d_lp, (size_t)n * 4));
+        HIPCK(sc.alloc(&d_visit, (size_t)n_nodes * 4));
+        HIPCK(sc.alloc(&d_lo, (size_t)n_nodes * 16));
+        HIPCK(sc.alloc(&d_hi, (size_t)n_nodes * 16));
+        HIPCK(hipMemsetAsync(d_visit, 0, (size_t)n_nodes * 4, stream));
+        k_parents_of<<<(n_nodes + 255) / 256, 256, 0, stream>>>(r.hnodes, n_nodes, d_np, d_lp);
+        k_refit_records<<<(n + 255) / 256, 256, 0, stream>>>((int)n, r.tris, r.pad_abs, r.hnodes, d_np, d_lp, d_visit, d_lo, d_hi, r.nodes);
+    }
+    return sync_ok(stream, "fp32 nodes", err);
+}
+
+bool ensure_hnodes(LbvhResult& r, hipStream_t stream, std::string& err)
+{
+    if (r.hnodes || r.n_tris == 0) return true;
+    if (!r.nodes) { err = "fp16 nodes: neither node array is present"; return false; }
+    Scratch sc;
+    float* d_area;
+    HIPCK(sc.alloc(&d_area, 16));
+    HIPCK(hipMemsetAsync(d_area, 0, 16, stream));
+    HIPCK(hipMalloc((void**)&r.hnodes, (size_t)r.n_nodes * sizeof(HNode)));
+    k_half_nodes<<<(r.n_nodes + 255) / 256, 256, 0, stream>>>(r.nodes, r.n_nodes, r.hspace, r.hnodes, d_area);
+    return sync_ok(stream, "fp16 nodes", err);
+}
+
+// experiment formats, derived from the fp32 nodes on first use by a kernel variant that reads them
+bool ensure_qnodes(LbvhResult& r, hipStream_t stream, std::string& err)
+{
+    if (r.qnodes || r.n_tris == 0) return true;
+    if (!ensure_nodes(r, stream, err)) return false;
+    HIPCK(hipMalloc((void**)&r.qnodes, (size_t)r.n_nodes * sizeof(QNode)));
+    k_quant_nodes<<<(r.n_nodes + 255) / 256, 256, 0, stream>>>(r.nodes, r.n_nodes, r.grid, r.qnodes);
+    return sync_ok(stream, "grid nodes", err);
+}
+
+bool ensure_cnodes(LbvhResult& r, hipStream_t stream, std::string& err)
+{
+    if (r.cnodes || r.n_tris == 0) return true;
+    if (!ensure_nodes(r, stream, err)) return false;
+    HIPCK(hipMalloc((void**)&r.cnodes, (size_t)r.n_nodes * sizeof(BvhNode)));
+    k_centre_nodes<<<(r.n_nodes + 255) / 256, 256, 0, stream>>>(r.nodes, r.n_nodes, r.cnodes);
+    return sync_ok(stream, "centre nodes", err);
+}
+
+// (Morton code, original triangle index) of every leaf slot, as the sort saw them: recomputed from the records, HOST outputs
+bool read_morton(const LbvhResult& r, hipStream_t stream, uint32_t* h_codes, uint32_t* h_prims, std::string& err)
+{
+    if (r.n_tris == 0) return true;
+    Scratch sc;
+    uint32_t *d_k, *d_p;
+    HIPCK(sc.alloc(&d_k, (size_t)r.n_tris * 4));
+    HIPCK(sc.alloc(&d_p, (size_t)r.n_tris * 4));
+    Bounds6 b;
+    for (int k = 0; k < 3; k++) { b.v[k] = r.scene_lo[k]; b.v[3 + k] = r.scene_hi[k]; }
+    k_morton_of_records<<<(r.n_tris + 255) / 256, 256, 0, stream>>>(r.tris, r.n_tris, r.pad_abs, b, d_k, d_p);
+    HIPCK(hipGetLastError());
+    HIPCK(hipMemcpyAsync(h_codes, d_k, (size_t)r.n_tris * 4, hipMemcpyDeviceToHost, stream));
+    HIPCK(hipMemcpyAsync(h_prims, d_p, (size_t)r.n_tris * 4, hipMemcpyDeviceToHost, stream));
+    HIPCK(hipStreamSynchronize(stream));
+    return true;
+}
+
+size_t scene_device_bytes(const LbvhResult& r)
+{
+    size_t b = 0;
+    if (r.nodes) b += (size_t)r.n_nodes * sizeof(BvhNode);
+    if (r.hnodes) b += (size_t)r.n_nodes * sizeof(HNode);
+    if (r.qnodes) b += (size_t)r.n_nodes * sizeof(QNode);
+    if (r.cnodes) b += (size_t)r.n_nodes * sizeof(BvhNode);
+    if (r.top_nodes) b += (size_t)kTopNodesMax * (sizeof(HNode) + sizeof(uint32_t));
+    if (r.tris) b += (size_t)r.n_tris * sizeof(TriRecord);
+    if (r.shade) b += (size_t)r.n_tris * sizeof(float4);
+    if (r.wrecs) b += (size_t)r.n_wrecs * 48u;
+    return b;
 }
 
 bool build_lbvh(const float* h_verts_xyzw, size_t n_verts, const uint32_t* h_idx, size_t n_tris,

@@ -109,6 +109,7 @@ bool build_wide4(LbvhResult& r, hipStream_t stream, std::string& err)
     const auto t0 = std::chrono::steady_clock::now();
     const uint32_t n = r.n_tris;
     if (n == 0) return true;
+    if (!ensure_nodes(r, stream, err)) return false;
     std::vector<BvhNode> nodes(r.n_nodes);
     std::vector<TriRecord> tris(n);
     hipError_t e = hipMemcpyAsync(nodes.data(), r.nodes, (size_t)r.n_nodes * sizeof(BvhNode), hipMemcpyDeviceToHost, stream);

@@ -126,6 +126,10 @@ typedef struct pt_bvh_info {
     uint32_t half_node_bytes; /* bytes of the fp16 node array (32 B per node)  */
     float    half_area_ratio; /* summed child-box area with fp16 planes / with fp32 planes (>= 1) */
     float    half_box_inflation; /* mean over the child boxes of their own fp16 / fp32 area (>= 1): large where geometry is finer than the fp16 planes */
+    uint64_t device_bytes;    /* bytes of device memory the scene's arrays hold right now (ABI version 4).  A scene keeps ONE node array — the one
+                               * its kernel reads: fp16 nodes (32 B per node) or fp32 nodes (64 B) — plus triangle records (48 B) and shading
+                               * records (16 B); node_bytes / half_node_bytes above are the SIZES of the two formats, whichever is resident.
+                               * The other array, and the experiment formats, are rebuilt on first use (a ray query, pt_set_tuning) and count from then on. */
 } pt_bvh_info;
 
 /* ---- lifetime -------------------------------------------------------------

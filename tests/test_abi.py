@@ -40,8 +40,8 @@ def test_exports_every_declared_symbol(lib):
     out = subprocess.run(["nm", "-D", "--defined-only", _native.hip_library_path()], capture_output=True, text=True, check=True).stdout
     exported = set(re.findall(r" T (pt_[a-z_]+)", out))
     assert exported == set(syms) | set(hooks)
-    assert lib.pt_abi_version() == 3 == _native.ABI_VERSION
-    assert C.sizeof(_native.Stats) == 96 and C.sizeof(_native.BvhInfo) == 80
+    assert lib.pt_abi_version() == 4 == _native.ABI_VERSION
+    assert C.sizeof(_native.Stats) == 96 and C.sizeof(_native.BvhInfo) == 88
 
 
 def test_pod_layouts_match_the_reference():

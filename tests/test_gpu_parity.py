@@ -98,7 +98,7 @@ def both_modes(request, full, diffuse):
 
 def test_library_is_the_hip_one():
     L = _native.hip()
-    assert L.pt_abi_version() == 3
+    assert L.pt_abi_version() == 4
     assert _native.hip_library_path().endswith("libacgpt_hip.so")
 
 
@@ -110,7 +110,10 @@ def test_morton_sort_bit_exact(full):
     codes = np.zeros(T, np.uint32); prims = np.zeros(T, np.uint32)
     assert _native.hip().pt_read_morton(state.context, codes.ctypes.data, prims.ctypes.data) == 0
     # restatement of k_prepare / k_morton (fp32 throughout)
-    tri = v[idx][:, :, :3]
+    tri = v[idx][:, :, :3].astype(np.float32).copy()
+    # the corners the builder boxes: v0, v0 + e1, v0 + e2 with the record's rounded edges e = v - v0 (lbvh_build.hip record_aabb)
+    tri[:, 1] = (tri[:, 0] + (tri[:, 1] - tri[:, 0]).astype(np.float32)).astype(np.float32)
+    tri[:, 2] = (tri[:, 0] + (tri[:, 2] - tri[:, 0]).astype(np.float32)).astype(np.float32)
     lo = tri.min(axis=1); hi = tri.max(axis=1)
     pad_abs = np.float32(max(1.0, float(np.abs(v[:, :3]).max()))) * np.float32(1.0 / 524288.0)
     pad = np.maximum(np.float32(1e-5) * np.maximum(np.float32(1.0), np.maximum(np.abs(lo), np.abs(hi))), pad_abs).astype(np.float32)
@@ -136,6 +139,47 @@ def test_morton_sort_bit_exact(full):
     assert info.n_tris == T and info.n_nodes == T - 1
     assert np.allclose(np.array(info.scene_lo), slo) and np.allclose(np.array(info.scene_hi), shi)
     assert 8 <= info.stack_entries <= 64 and info.max_depth < info.stack_entries
+
+
+def test_a_scene_keeps_one_node_array(gpu_state_factory):
+    """the builder leaves ONE node array on the device — the one the chosen kernel reads (fp16: 32 B per node)
+    — next to the triangle and shading records; the fp32 nodes come back on first use (a ray query, an fp32 kernel variant)
+    from the topology and the records, and render the same bits as the fp16 kernel."""
+    L = _native.hip()
+    state, obj = gpu_state_factory(SCENE_FULL, width=48, height=48, direct_lighting=True, importance_sampling=True, spp=4, max_depth=4)
+    T = obj.getIndexBuffer().size // 3
+    info = pt.getBvhInfo(state)
+    assert info.half_node_bytes == 32 * (T - 1) and info.node_bytes == 64 * (T - 1) and info.tri_bytes == 48 * T
+    lean = info.half_node_bytes + info.tri_bytes + 16 * T
+    assert info.device_bytes == lean, "after pt_set_scene: fp16 nodes + triangle records + shading records, nothing else"
+    assert info.device_bytes <= 1.3 * (info.half_node_bytes + info.tri_bytes)      # bench.py's scene_bytes
+    p = make_params(48, 48, 4, 4, True, True)
+    want, _, st = _gpu_render(state, p)
+    assert L.pt_variant_name(int(st[0].variant)).find(b"fp16") >= 0
+    assert pt.getBvhInfo(state).device_bytes == lean, "rendering with the chosen kernel allocates no scene array"
+    # a ray query walks the fp32 nodes: rebuilt now, counted from now on
+    rays = random_rays(2000, 7)
+    t = np.zeros(2000, np.float32); prim = np.zeros(2000, np.uint32)
+    assert L.pt_trace_closest(state.context, rays.ctypes.data, 2000, t.ctypes.data, prim.ctypes.data) == 0
+    assert pt.getBvhInfo(state).device_bytes == lean + info.node_bytes
+    # ... and an fp32 kernel variant on those rebuilt nodes renders the fp16 kernel's bits
+    try:
+        assert L.pt_set_tuning(state.context, 0, 1) == 0
+        got, _, st = _gpu_render(state, p)
+        assert int(st[0].variant) == 1 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    finally:
+        assert L.pt_set_tuning(state.context, 0, -1) == 0
+    # a scene that is set while an fp32 variant is selected keeps the fp32 nodes instead
+    state2, _ = gpu_state_factory(SCENE_FULL, width=48, height=48, direct_lighting=True, importance_sampling=True, spp=4, max_depth=4)
+    assert L.pt_set_tuning(state2.context, 0, 1) == 0
+    pt.buildTheAccelarationStructure(state2, obj)
+    i2 = pt.getBvhInfo(state2)
+    assert i2.device_bytes == i2.node_bytes + i2.tri_bytes + 16 * T
+    got2, _, _ = _gpu_render(state2, p)
+    assert np.array_equal(got2.view(np.uint32), want.view(np.uint32))
+    assert L.pt_set_tuning(state2.context, 0, -1) == 0
+    got3, _, _ = _gpu_render(state2, p)          # back to the fp16 kernel: its nodes are derived from the fp32 ones on first use
+    assert np.array_equal(got3.view(np.uint32), want.view(np.uint32))
 
 
 def test_trace_closest_bit_exact(full):
