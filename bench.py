@@ -66,12 +66,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
+    ap.add_argument("--config", type=int, default=2, choices=[0, 2, 3, 5],
                     help="BASELINE.json config: 2 = diffuse Cornell, 1024 spp, 8 bounces (default, the headline); "
-                         "3 = glass + metal, 4096 spp, 16 bounces; 5 = 1.3 M-triangle stress scene, 256 spp, 8 bounces")
+                         "3 = glass + metal, 4096 spp, 16 bounces; 5 = 1.3 M-triangle stress scene, 256 spp, 8 bounces; "
+                         "0 = the one workload the reference's own program defines (PathTracerMain.cpp:43, 58-59, 653-657): cornell_box.obj, "
+                         "512x512, 128 spp per launch, maxDepth 4, direct lighting off, importance sampling off")
     ap.add_argument("--scene", default=None)
-    ap.add_argument("--width", type=int, default=WIDTH)
-    ap.add_argument("--height", type=int, default=HEIGHT)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--direct-lighting", type=int, default=None, choices=[0, 1], help="useDirectLighting (default: per config)")
+    ap.add_argument("--importance-sampling", type=int, default=None, choices=[0, 1], help="useImportanceSampling (default: per config)")
     ap.add_argument("--spp", type=int, default=SPP_PER_LAUNCH)
     ap.add_argument("--max-depth", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -86,16 +90,36 @@ def parse():
     ap.add_argument("--save", default="", help="write the final framebuffer as PPM (rank 0)")
     ap.add_argument("--save-accum", default="", help="write the final float4 accumulation buffer as .npy (rank 0)")
     a = ap.parse_args()
-    preset = {2: ("cornell_box_diffuse.obj", 8, 8), 3: ("cornell_box.obj", 32, 16), 5: ("stress_1m.obj", 2, 8)}[a.config]
+    preset = PRESETS[a.config]
     if a.scene is None:
         a.scene = preset[0]
     if a.steps is None:
         a.steps = preset[1]
     if a.max_depth is None:
         a.max_depth = preset[2]
+    if a.width is None:
+        a.width = preset[3]
+    if a.height is None:
+        a.height = preset[4]
+    if a.direct_lighting is None:
+        a.direct_lighting = preset[5]
+    if a.importance_sampling is None:
+        a.importance_sampling = preset[6]
     if a.cpu_spp <= 0:
-        a.cpu_spp = {2: 64, 3: 64, 5: 32}[a.config]      # ~10-20 s of CPU work on 16 host threads
+        a.cpu_spp = {0: 256, 2: 64, 3: 64, 5: 32}[a.config]      # ~10-20 s of CPU work on 16 host threads
     return a
+
+
+# config -> (scene, steps, maxDepth, width, height, direct lighting, importance sampling).  Config 0 is the reference program's own
+# start-up state (PathTracerMain.cpp:43 samples_per_launch 128, :58-59 512 x 512, :653-657 depth 4 / both toggles off); its 8
+# steps are 8 iterations of the reference's frame loop (:700-730), whose "Frame Render Time" print (:726) is one step.
+PRESETS = {0: ("cornell_box.obj", 8, 4, 512, 512, 0, 0), 2: ("cornell_box_diffuse.obj", 8, 8, WIDTH, HEIGHT, 1, 1),
+           3: ("cornell_box.obj", 32, 16, WIDTH, HEIGHT, 1, 1), 5: ("stress_1m.obj", 2, 8, WIDTH, HEIGHT, 1, 1)}
+
+
+def toggles_text(a):
+    return {(1, 1): "importance sampling + direct lighting", (1, 0): "direct lighting, uniform hemisphere sampling",
+            (0, 1): "importance sampling, no direct lighting", (0, 0): "no direct lighting, uniform hemisphere sampling (the reference's start-up toggles)"}[(int(a.direct_lighting), int(a.importance_sampling))]
 
 
 def scene_path(pt, name):
@@ -138,8 +162,8 @@ def cpu_baseline(pt, obj, params, cpu_spp):
     rays = st["radiance_rays"] + st["shadow_rays"]
     sc.close()
     return {"value": rays / secs / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
-            "sample": "%s %dx%d maxDepth %d IS+DL, %d spp x 1 frame (%.1f s, %d rays)" %
-                      (os.path.basename(obj.path), q.width, q.height, q.maxDepth, cpu_spp, secs, rays)}, rays / max(1, q.width * q.height * cpu_spp)
+            "sample": "%s %dx%d maxDepth %d DL %d IS %d, %d spp x 1 frame (%.1f s, %d rays)" %
+                      (os.path.basename(obj.path), q.width, q.height, q.maxDepth, int(q.useDirectLighting), int(q.useImportanceSampling), cpu_spp, secs, rays)}, rays / max(1, q.width * q.height * cpu_spp)
 
 
 def primary_miss_fraction(p, info):
@@ -197,8 +221,10 @@ def roofline_block(a, info, world, fuse, kernel_ms, traced_per_launch, counted_p
     valu_tf = algo_flops / ksec / 1e12 if ksec > 0 else 0.0
     valu_tf_counted = counted_per_launch * f_ray / ksec / 1e12 if ksec > 0 else 0.0
     summ, src = pmc_summary(a.config)
-    default_cmd = (a.scene == {2: "cornell_box_diffuse.obj", 3: "cornell_box.obj", 5: "stress_1m.obj"}[a.config]
-                   and (a.width, a.height, a.spp) == (WIDTH, HEIGHT, SPP_PER_LAUNCH) and world == 1 and a.variant < 0
+    pre = PRESETS[a.config]
+    default_cmd = (a.scene == pre[0] and (a.width, a.height, a.spp) == (pre[3], pre[4], SPP_PER_LAUNCH) and world == 1 and a.variant < 0
+                   and (int(getattr(a, "direct_lighting", pre[5])), int(getattr(a, "importance_sampling", pre[6]))) == (pre[5], pre[6])
+                   and getattr(a, "max_depth", pre[2]) == pre[2]
                    and not a.blocks_per_cu and a.fuse == 8 and a.chunks == 0)
     traffic, measured, fabric, dropped = None, None, None, None
     if summ and default_cmd:
@@ -284,7 +310,7 @@ def main():
     state = pt.PathTracerState()
     pt.createDeviceContext(state, local_rank)
     pt.buildTheAccelarationStructure(state, obj)
-    p = make_params(a.width, a.height, a.spp, a.max_depth, True, True)
+    p = make_params(a.width, a.height, a.spp, a.max_depth, bool(a.direct_lighting), bool(a.importance_sampling))
     p.handle = state.params.handle
     accum = torch.zeros((a.height, a.width, 4), dtype=torch.float32, device=dev)
     fb = torch.zeros((a.height, a.width, 4), dtype=torch.uint8, device=dev)
@@ -391,8 +417,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "%s (%d triangles), %dx%d, %d spp per step x %d steps, maxDepth %d, importance sampling + direct lighting"
-                                   % (a.scene, info.n_tris, a.width, a.height, a.spp, a.steps, a.max_depth),
+            "config": {"workload": "%s (%d triangles), %dx%d, %d spp per step x %d steps, maxDepth %d, %s"
+                                   % (a.scene, info.n_tris, a.width, a.height, a.spp, a.steps, a.max_depth, toggles_text(a)),
+                       "baseline_config": ("the reference program's own start-up workload (PathTracerMain.cpp:43, 58-59, 653-657); a step is one iteration of its frame loop (:700-730)"
+                                           if a.config == 0 else "BASELINE.json configs[%d]" % (a.config - 1)),
                        "math": ("fast: the arithmetic of the reference's own build (nvcc --use_fast_math, CMakeLists.txt:267): v_rcp / v_sqrt / v_rsq / v_sin / v_cos in the shading code; traversal and triangle test as in ieee mode"
                                 if math_mode == _native.MATH_FAST else "ieee: correctly rounded division / square root and libm sincosf / acosf in the shading code (the CPU oracle's level)"),
                        "steps_per_kernel_launch": fuse, "kernel_launches": n_launches,

@@ -120,6 +120,23 @@ def image_mse_trimmed(a, b, drop):
     return float(kept.sum() / per_pixel.size)
 
 
+def flip_report(a, b, pixel_tol=1e-6):
+    """Two renders of the same samples at two arithmetic levels in uniform-hemisphere mode (image_mse_trimmed above says why single
+    paths flip there): instead of trimming the worst pixels away silently, COUNT them.  A pixel is "out" when its squared error
+    (mean over the channels, clamped linear radiance) exceeds pixel_tol — i.e. when it differs by more than 1e-3 of full scale.
+    Returns a dict: mse (whole image), n_out, frac_out, mse_rest (the mean squared error of the other pixels, over the whole pixel
+    count), mean_a / mean_b (whole image) and rest_mean_a / rest_mean_b (over the pixels that are not out)."""
+    x = np.clip(a[..., :3].astype(np.float64), 0.0, 1.0)
+    y = np.clip(b[..., :3].astype(np.float64), 0.0, 1.0)
+    per_pixel = np.mean((x - y) ** 2, axis=-1)
+    out = per_pixel > pixel_tol
+    n = per_pixel.size
+    rest = ~out
+    return {"mse": float(per_pixel.mean()), "n_out": int(out.sum()), "frac_out": float(out.sum()) / n,
+            "mse_rest": float(per_pixel[rest].sum() / n), "mean_a": float(x.mean()), "mean_b": float(y.mean()),
+            "rest_mean_a": float(x[rest].mean()) if rest.any() else 0.0, "rest_mean_b": float(y[rest].mean()) if rest.any() else 0.0}
+
+
 def image_mse(a, b):
     """Per-channel MSE of linear accumulation buffers clamped to [0,1] (SURVEY.md §8d parity metric)."""
     x = np.clip(a[..., :3].astype(np.float64), 0.0, 1.0)
