@@ -240,6 +240,7 @@ def roofline_block(a, info, world, fuse, kernel_ms, traced_per_launch, counted_p
                         "steps_per_launch_profiled": summ.get("steps_per_kernel_launch", 8),
                         "ta_busy": der.get("ta_busy_frac(256 TAs)"),
                         "valu_issue_busy": der.get("valu_issue_busy_frac(2cyc/instr,1024 SIMDs)"),
+                        "valu_issue_busy_mix": der.get("valu_issue_busy_mix"), "valu_issue_busy_ubench": der.get("valu_issue_busy_ubench"),
                         "lane_utilisation": der.get("valu_lane_utilisation"),
                         "l2_hit": der.get("l2_hit_rate"), "l1_miss_per_access": der.get("l1_miss_per_access"),
                         "hbm_GBps": (traffic / (prof_ms * 1e-3) / 1e9) if traffic and prof_ms else None}
@@ -262,6 +263,15 @@ def roofline_block(a, info, world, fuse, kernel_ms, traced_per_launch, counted_p
          "hbm_model": {"algorithmic_bytes_per_ray": b_ray, "algorithmic_bytes_per_launch": algo_bytes, "GBps": model_gbs,
                        "note": "SURVEY.md 8d byte model; for a cache-resident scene these bytes are served by L1/L2/Infinity Cache, so this is not an HBM fraction"},
          "valu_model": {"algorithmic_flops_per_ray": f_ray, "TFLOPs": valu_tf, "frac_of_fp32_vector_peak": valu_tf / FP32_PEAK_TFLOPS}}
+    if measured and measured.get("valu_issue_busy_mix") is not None and measured.get("ta_busy") is not None:
+        # what binds, as measured: the SIMDs' issue slots (vector instruction count priced by opcode class: full / half / quarter rate
+        # at 2 / 4 / 8 cycles; tools/valu_mix.py) against the texture-address units, at the fraction of lanes that do useful work
+        vi, ta = measured["valu_issue_busy_mix"], measured["ta_busy"]
+        r["issue"] = {"valu_issue_busy_mix": vi, "ta_busy": ta, "lane_utilisation": measured.get("lane_utilisation"),
+                      "valu_issue_busy_ubench": measured.get("valu_issue_busy_ubench"),
+                      "note": "valu_issue_busy_mix: SQ_INSTS_VALU priced by opcode class (2 / 4 / 8 cycles) over 1024 SIMDs x kernel cycles; _ubench: the same count at the "
+                              "cycles profiles/r02_ubench_valu.txt measures per class in isolation (upper bound); ta_busy: TA_TA_BUSY over 256 units"}
+        r["bound_measured"] = "vector issue" if vi >= ta else "texture-address path"
     if dropped:
         r["profile_dropped"] = dropped
     if fabric:
@@ -408,6 +418,7 @@ def main():
                       % ("1080p" if (a.width, a.height) == (WIDTH, HEIGHT) else "%dx%d" % (a.width, a.height), a.spp * a.steps, a.max_depth),
             "value": all_rays / elapsed / 1e6,
             "unit": "Mray/s",
+            "Mray_per_s_entering_scene": (all_rays - tot_culled) / elapsed / 1e6,      # the rays the kernel traverses: `value` minus camera rays settled at the scene box
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed * 1e3 / a.steps,
             "ms_per_frame": elapsed * 1e3,

@@ -9,6 +9,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
@@ -54,6 +55,20 @@ def main():
             der["clock_ghz"] = cyc / (out["kernel_stats"]["avg_ms"] * 1e6)
         if g("SQ_INSTS_VALU"):
             der["valu_issue_busy_frac(2cyc/instr,1024 SIMDs)"] = g("SQ_INSTS_VALU") * 2.0 / (cyc * 1024)
+            # the same count priced by opcode class (tools/valu_mix.py: static mix of the kernel that ran, BVH loop and the rest blended by
+            # their share of the wave-time): _mix at the datasheet's 2 / 4 / 8 cycles for full / half / quarter rate, _ubench at the
+            # cycles the microbenchmark measures for each class in isolation (an upper bound: it can exceed 1, classes overlap in a mixed stream)
+            try:
+                import valu_mix
+                kname = out.get("kernel_stats", {}).get("name", "")
+                inst = kname[kname.index("k_render"):kname.index("(ptd::")] if "k_render" in kname and "(ptd::" in kname else kern
+                lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "acgpathtracing_amd", os.environ.get("ACGPT_HIP_LIB", "libacgpt_hip.so"))
+                vm = valu_mix.kernel_mix(lib, inst)
+                out["valu_mix"] = vm
+                der["valu_issue_busy_mix"] = g("SQ_INSTS_VALU") * vm["cycles_per_valu_spec"] / (cyc * 1024)
+                der["valu_issue_busy_ubench"] = g("SQ_INSTS_VALU") * vm["cycles_per_valu_priced"] / (cyc * 1024)
+            except Exception as e:
+                out["valu_mix"] = {"error": str(e)}
         if g("TA_TA_BUSY_sum"):
             der["ta_busy_frac(256 TAs)"] = g("TA_TA_BUSY_sum") / (cyc * 256)
     if g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):

@@ -55,6 +55,16 @@ BODY(k_bfi, A_BFI) BODY(k_min3, A_MIN3) BODY(k_sub, A_SUB) BODY(k_xor, A_XOR) BO
 #define A_MED3(n) "v_med3_f32 %" #n ", %" #n ", %8, %9\n"
 BODY(k_alignbit, A_ALIGNBIT) BODY(k_perm, A_PERM) BODY(k_med3, A_MED3)
 BODY(k_fmamix, A_FMAMIX) BODY(k_fmamixh, A_FMAMIXH) BODY(k_cvth, A_CVTH)
+// round 4: what a plane-sharing node visit would add (packed 16-bit integer max as a NaN router, fp16 interval packing), and two
+// mixed streams: do the class costs add when full- and half-rate instructions alternate?
+#define A_PKMAXI(n) "v_pk_max_i16 %" #n ", %" #n ", %10\n"
+#define A_PKMAXU(n) "v_pk_max_u16 %" #n ", %" #n ", %10\n"
+#define A_CVTPK(n)  "v_cvt_pkrtz_f16_f32 %" #n ", %" #n ", %8\n"
+#define A_OR(n)     "v_or_b32 %" #n ", %" #n ", %10\n"
+#define A_MIXFMA(n) "v_fma_mix_f32 %" #n ", %" #n ", %8, %9 op_sel_hi:[1,0,0]\nv_fma_f32 %" #n ", %" #n ", %8, %9\n"
+#define A_MAXFMA(n) "v_max_f32 %" #n ", %" #n ", %8\nv_fma_f32 %" #n ", %" #n ", %8, %9\n"
+#define A_MIXABS(n) "v_fma_mix_f32 %" #n ", |%" #n "|, %8, %9 op_sel_hi:[1,0,0]\n"
+BODY(k_pkmaxi, A_PKMAXI) BODY(k_pkmaxu, A_PKMAXU) BODY(k_cvtpk, A_CVTPK) BODY(k_or, A_OR) BODY(k_mixfma, A_MIXFMA) BODY(k_maxfma, A_MAXFMA) BODY(k_mixabs, A_MIXABS)
 BODY(k_cmp, A_CMP) BODY(k_rcp, A_RCP) BODY(k_mov, A_MOV) BODY(k_lshlor, A_LSHLOR) BODY(k_andor, A_ANDOR)
 
 __global__ void __launch_bounds__(256) k_cmps(int iters, float* out) {
@@ -236,7 +246,9 @@ int main()
                        {"1 v_cmp vcc + 4 v_cndmask (x0.2)", k_cmp_cnd4}, {"1 v_cmp sgpr + 4 v_cndmask (x0.2)", k_cmps_cnd4}, {"1 v_cmp vcc + 4 cndmask_e64 vcc", k_cmp_cnd4_e64}, {"1 v_cmp vcc + 4 cndmask dst!=src", k_cmp_cnd4_d},
                        {"v_pk_fma_f32 (2 fma)", k_pkfma}, {"v_pk_mul_f32 (2 mul)", k_pkmul}, {"v_pk_add_f32 (2 add)", k_pkadd},
                        {"v_lshlrev_b64", k_shl64}, {"v_lshl_add_u64", k_lshladd64}, {"v_mad_u64_u32", k_mad64}, {"v_mul_u32_u24", k_mul24}, {"v_mul_lo_u32", k_mullo},
-                       {"v_bfi_b32", k_bfi}, {"v_min3_f32", k_min3}, {"v_sub_f32", k_sub}, {"v_xor_b32", k_xor}, {"v_mad_u32_u24", k_mad24}, {"v_rcp_f32", k_rcp}, {"v_mov_b32", k_mov}, {"v_lshl_or_b32", k_lshlor}, {"v_and_or_b32", k_andor}, {"s_and_b64 (scalar)", k_salu}};
+                       {"v_bfi_b32", k_bfi}, {"v_min3_f32", k_min3}, {"v_sub_f32", k_sub}, {"v_xor_b32", k_xor}, {"v_mad_u32_u24", k_mad24}, {"v_rcp_f32", k_rcp}, {"v_mov_b32", k_mov}, {"v_lshl_or_b32", k_lshlor}, {"v_and_or_b32", k_andor}, {"s_and_b64 (scalar)", k_salu},
+                       {"v_pk_max_i16", k_pkmaxi}, {"v_pk_max_u16", k_pkmaxu}, {"v_cvt_pkrtz_f16_f32", k_cvtpk}, {"v_or_b32", k_or}, {"v_fma_mix_f32 |src0| (abs modifier)", k_mixabs},
+                       {"PAIR v_fma_mix_f32 + v_fma_f32", k_mixfma}, {"PAIR v_max_f32 + v_fma_f32", k_maxfma}};
     const int iters = 2000;
     printf("%-26s %10s %10s %10s %10s   SIMD cycles per wave-instruction\n", "instruction", "1 w/SIMD", "2 w/SIMD", "4 w/SIMD", "8 w/SIMD");
     for (const Desc& kd : ks) {
