@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(256) NAME(int iters, float* out) { \
     for (int i = 0; i < iters; i++) { \
         _Pragma("unroll") for (int k = 0; k < 8; k++) { \
             asm volatile(ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7) \
-                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "v"(m) : "vcc"); \
+                : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "v"(b), "v"(m) : "vcc", "s20", "s21"); \
         } \
     } \
     if (r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 == 12345.678f) out[0] = r0; \
@@ -229,6 +229,110 @@ __global__ void __launch_bounds__(256) k_salu(int iters, float* out) {
     if (x == 0x1234567 && c == 7) out[0] = 1.0f;
 }
 
+#define PAIR_ALT_0 1
+#define PAIR_ALT_1 0
+#define PAIR_ALT_2 3
+#define PAIR_ALT_3 2
+#define PAIR_ALT_4 5
+#define PAIR_ALT_5 4
+#define PAIR_ALT_6 7
+#define PAIR_ALT_7 6
+#define PAIR_CALL(M, n) M(n)
+// round 4: PAIRS — which instructions share an execution pipe?  cost(pair) ~ cost(a) + cost(b): same pipe; ~ max(cost(a), cost(b)): they overlap.
+// The two instructions of a pair alternate on DIFFERENT registers (n and n^1 of the eight), so that no dependence links them.
+#define A_PAIR_ALIGNBIT_FMA(n) A_ALIGNBIT(n) PAIR_CALL(A_FMA, PAIR_ALT_##n)
+BODY(k_pair_alignbit_fma, A_PAIR_ALIGNBIT_FMA)
+#define A_PAIR_MAX_FMA(n) A_MAX(n) PAIR_CALL(A_FMA, PAIR_ALT_##n)
+BODY(k_pair_max_fma, A_PAIR_MAX_FMA)
+#define A_PAIR_MAX3_FMA(n) A_MAX3(n) PAIR_CALL(A_FMA, PAIR_ALT_##n)
+BODY(k_pair_max3_fma, A_PAIR_MAX3_FMA)
+#define A_PAIR_MIN3_FMA(n) A_MIN3(n) PAIR_CALL(A_FMA, PAIR_ALT_##n)
+BODY(k_pair_min3_fma, A_PAIR_MIN3_FMA)
+#define A_PAIR_CMPS_FMA(n) A_CMPS(n) PAIR_CALL(A_FMA, PAIR_ALT_##n)
+BODY(k_pair_cmps_fma, A_PAIR_CMPS_FMA)
+#define A_PAIR_PKMAXI_FMA(n) A_PKMAXI(n) PAIR_CALL(A_FMA, PAIR_ALT_##n)
+BODY(k_pair_pkmaxi_fma, A_PAIR_PKMAXI_FMA)
+#define A_PAIR_SHL_FMA(n) A_SHL(n) PAIR_CALL(A_FMA, PAIR_ALT_##n)
+BODY(k_pair_shl_fma, A_PAIR_SHL_FMA)
+#define A_PAIR_ADDU_FMA(n) A_ADDU(n) PAIR_CALL(A_FMA, PAIR_ALT_##n)
+BODY(k_pair_addu_fma, A_PAIR_ADDU_FMA)
+#define A_PAIR_AND_FMA(n) A_AND(n) PAIR_CALL(A_FMA, PAIR_ALT_##n)
+BODY(k_pair_and_fma, A_PAIR_AND_FMA)
+#define A_PAIR_MOV_FMA(n) A_MOV(n) PAIR_CALL(A_FMA, PAIR_ALT_##n)
+BODY(k_pair_mov_fma, A_PAIR_MOV_FMA)
+#define A_PAIR_CVTH_FMA(n) A_CVTH(n) PAIR_CALL(A_FMA, PAIR_ALT_##n)
+BODY(k_pair_cvth_fma, A_PAIR_CVTH_FMA)
+#define A_PAIR_FMAMIX_FMA(n) A_FMAMIX(n) PAIR_CALL(A_FMA, PAIR_ALT_##n)
+BODY(k_pair_fmamix_fma, A_PAIR_FMAMIX_FMA)
+#define A_PAIR_MUL_FMA(n) A_MUL(n) PAIR_CALL(A_FMA, PAIR_ALT_##n)
+BODY(k_pair_mul_fma, A_PAIR_MUL_FMA)
+#define A_PAIR_BFI_FMA(n) A_BFI(n) PAIR_CALL(A_FMA, PAIR_ALT_##n)
+BODY(k_pair_bfi_fma, A_PAIR_BFI_FMA)
+#define A_PAIR_RCP_FMA(n) A_RCP(n) PAIR_CALL(A_FMA, PAIR_ALT_##n)
+BODY(k_pair_rcp_fma, A_PAIR_RCP_FMA)
+#define A_PAIR_LSHLOR_FMA(n) A_LSHLOR(n) PAIR_CALL(A_FMA, PAIR_ALT_##n)
+BODY(k_pair_lshlor_fma, A_PAIR_LSHLOR_FMA)
+#define A_PAIR_ALIGNBIT_MAX(n) A_ALIGNBIT(n) PAIR_CALL(A_MAX, PAIR_ALT_##n)
+BODY(k_pair_alignbit_max, A_PAIR_ALIGNBIT_MAX)
+#define A_PAIR_MAX3_MAX(n) A_MAX3(n) PAIR_CALL(A_MAX, PAIR_ALT_##n)
+BODY(k_pair_max3_max, A_PAIR_MAX3_MAX)
+#define A_PAIR_MIN3_MAX(n) A_MIN3(n) PAIR_CALL(A_MAX, PAIR_ALT_##n)
+BODY(k_pair_min3_max, A_PAIR_MIN3_MAX)
+#define A_PAIR_CMPS_MAX(n) A_CMPS(n) PAIR_CALL(A_MAX, PAIR_ALT_##n)
+BODY(k_pair_cmps_max, A_PAIR_CMPS_MAX)
+#define A_PAIR_PKMAXI_MAX(n) A_PKMAXI(n) PAIR_CALL(A_MAX, PAIR_ALT_##n)
+BODY(k_pair_pkmaxi_max, A_PAIR_PKMAXI_MAX)
+#define A_PAIR_SHL_MAX(n) A_SHL(n) PAIR_CALL(A_MAX, PAIR_ALT_##n)
+BODY(k_pair_shl_max, A_PAIR_SHL_MAX)
+#define A_PAIR_ADDU_MAX(n) A_ADDU(n) PAIR_CALL(A_MAX, PAIR_ALT_##n)
+BODY(k_pair_addu_max, A_PAIR_ADDU_MAX)
+#define A_PAIR_AND_MAX(n) A_AND(n) PAIR_CALL(A_MAX, PAIR_ALT_##n)
+BODY(k_pair_and_max, A_PAIR_AND_MAX)
+#define A_PAIR_MOV_MAX(n) A_MOV(n) PAIR_CALL(A_MAX, PAIR_ALT_##n)
+BODY(k_pair_mov_max, A_PAIR_MOV_MAX)
+#define A_PAIR_CVTH_MAX(n) A_CVTH(n) PAIR_CALL(A_MAX, PAIR_ALT_##n)
+BODY(k_pair_cvth_max, A_PAIR_CVTH_MAX)
+#define A_PAIR_FMAMIX_MAX(n) A_FMAMIX(n) PAIR_CALL(A_MAX, PAIR_ALT_##n)
+BODY(k_pair_fmamix_max, A_PAIR_FMAMIX_MAX)
+#define A_PAIR_MUL_MAX(n) A_MUL(n) PAIR_CALL(A_MAX, PAIR_ALT_##n)
+BODY(k_pair_mul_max, A_PAIR_MUL_MAX)
+#define A_PAIR_BFI_MAX(n) A_BFI(n) PAIR_CALL(A_MAX, PAIR_ALT_##n)
+BODY(k_pair_bfi_max, A_PAIR_BFI_MAX)
+#define A_PAIR_RCP_MAX(n) A_RCP(n) PAIR_CALL(A_MAX, PAIR_ALT_##n)
+BODY(k_pair_rcp_max, A_PAIR_RCP_MAX)
+#define A_PAIR_LSHLOR_MAX(n) A_LSHLOR(n) PAIR_CALL(A_MAX, PAIR_ALT_##n)
+BODY(k_pair_lshlor_max, A_PAIR_LSHLOR_MAX)
+#define A_PAIR_ALIGNBIT_FMAMIX(n) A_ALIGNBIT(n) PAIR_CALL(A_FMAMIX, PAIR_ALT_##n)
+BODY(k_pair_alignbit_fmamix, A_PAIR_ALIGNBIT_FMAMIX)
+#define A_PAIR_MAX_FMAMIX(n) A_MAX(n) PAIR_CALL(A_FMAMIX, PAIR_ALT_##n)
+BODY(k_pair_max_fmamix, A_PAIR_MAX_FMAMIX)
+#define A_PAIR_MAX3_FMAMIX(n) A_MAX3(n) PAIR_CALL(A_FMAMIX, PAIR_ALT_##n)
+BODY(k_pair_max3_fmamix, A_PAIR_MAX3_FMAMIX)
+#define A_PAIR_MIN3_FMAMIX(n) A_MIN3(n) PAIR_CALL(A_FMAMIX, PAIR_ALT_##n)
+BODY(k_pair_min3_fmamix, A_PAIR_MIN3_FMAMIX)
+#define A_PAIR_CMPS_FMAMIX(n) A_CMPS(n) PAIR_CALL(A_FMAMIX, PAIR_ALT_##n)
+BODY(k_pair_cmps_fmamix, A_PAIR_CMPS_FMAMIX)
+#define A_PAIR_PKMAXI_FMAMIX(n) A_PKMAXI(n) PAIR_CALL(A_FMAMIX, PAIR_ALT_##n)
+BODY(k_pair_pkmaxi_fmamix, A_PAIR_PKMAXI_FMAMIX)
+#define A_PAIR_SHL_FMAMIX(n) A_SHL(n) PAIR_CALL(A_FMAMIX, PAIR_ALT_##n)
+BODY(k_pair_shl_fmamix, A_PAIR_SHL_FMAMIX)
+#define A_PAIR_ADDU_FMAMIX(n) A_ADDU(n) PAIR_CALL(A_FMAMIX, PAIR_ALT_##n)
+BODY(k_pair_addu_fmamix, A_PAIR_ADDU_FMAMIX)
+#define A_PAIR_AND_FMAMIX(n) A_AND(n) PAIR_CALL(A_FMAMIX, PAIR_ALT_##n)
+BODY(k_pair_and_fmamix, A_PAIR_AND_FMAMIX)
+#define A_PAIR_MOV_FMAMIX(n) A_MOV(n) PAIR_CALL(A_FMAMIX, PAIR_ALT_##n)
+BODY(k_pair_mov_fmamix, A_PAIR_MOV_FMAMIX)
+#define A_PAIR_CVTH_FMAMIX(n) A_CVTH(n) PAIR_CALL(A_FMAMIX, PAIR_ALT_##n)
+BODY(k_pair_cvth_fmamix, A_PAIR_CVTH_FMAMIX)
+#define A_PAIR_MUL_FMAMIX(n) A_MUL(n) PAIR_CALL(A_FMAMIX, PAIR_ALT_##n)
+BODY(k_pair_mul_fmamix, A_PAIR_MUL_FMAMIX)
+#define A_PAIR_BFI_FMAMIX(n) A_BFI(n) PAIR_CALL(A_FMAMIX, PAIR_ALT_##n)
+BODY(k_pair_bfi_fmamix, A_PAIR_BFI_FMAMIX)
+#define A_PAIR_RCP_FMAMIX(n) A_RCP(n) PAIR_CALL(A_FMAMIX, PAIR_ALT_##n)
+BODY(k_pair_rcp_fmamix, A_PAIR_RCP_FMAMIX)
+#define A_PAIR_LSHLOR_FMAMIX(n) A_LSHLOR(n) PAIR_CALL(A_FMAMIX, PAIR_ALT_##n)
+BODY(k_pair_lshlor_fmamix, A_PAIR_LSHLOR_FMAMIX)
+
 typedef void (*Kern)(int, float*);
 struct Desc { const char* name; Kern k; };
 
@@ -248,7 +352,53 @@ int main()
                        {"v_lshlrev_b64", k_shl64}, {"v_lshl_add_u64", k_lshladd64}, {"v_mad_u64_u32", k_mad64}, {"v_mul_u32_u24", k_mul24}, {"v_mul_lo_u32", k_mullo},
                        {"v_bfi_b32", k_bfi}, {"v_min3_f32", k_min3}, {"v_sub_f32", k_sub}, {"v_xor_b32", k_xor}, {"v_mad_u32_u24", k_mad24}, {"v_rcp_f32", k_rcp}, {"v_mov_b32", k_mov}, {"v_lshl_or_b32", k_lshlor}, {"v_and_or_b32", k_andor}, {"s_and_b64 (scalar)", k_salu},
                        {"v_pk_max_i16", k_pkmaxi}, {"v_pk_max_u16", k_pkmaxu}, {"v_cvt_pkrtz_f16_f32", k_cvtpk}, {"v_or_b32", k_or}, {"v_fma_mix_f32 |src0| (abs modifier)", k_mixabs},
-                       {"PAIR v_fma_mix_f32 + v_fma_f32", k_mixfma}, {"PAIR v_max_f32 + v_fma_f32", k_maxfma}};
+                       {"PAIR v_fma_mix_f32 + v_fma_f32", k_mixfma}, {"PAIR v_max_f32 + v_fma_f32", k_maxfma},
+                       {"PAIR v_alignbit_b32 + v_fma_f32", k_pair_alignbit_fma},
+                       {"PAIR v_max_f32 + v_fma_f32", k_pair_max_fma},
+                       {"PAIR v_max3_f32 + v_fma_f32", k_pair_max3_fma},
+                       {"PAIR v_min3_f32 + v_fma_f32", k_pair_min3_fma},
+                       {"PAIR v_cmp_lt_f32 sgpr + v_fma_f32", k_pair_cmps_fma},
+                       {"PAIR v_pk_max_i16 + v_fma_f32", k_pair_pkmaxi_fma},
+                       {"PAIR v_lshlrev_b32 + v_fma_f32", k_pair_shl_fma},
+                       {"PAIR v_add_u32 + v_fma_f32", k_pair_addu_fma},
+                       {"PAIR v_and_b32 + v_fma_f32", k_pair_and_fma},
+                       {"PAIR v_mov_b32 + v_fma_f32", k_pair_mov_fma},
+                       {"PAIR v_cvt_f32_f16 + v_fma_f32", k_pair_cvth_fma},
+                       {"PAIR v_fma_mix_f32 + v_fma_f32", k_pair_fmamix_fma},
+                       {"PAIR v_mul_f32 + v_fma_f32", k_pair_mul_fma},
+                       {"PAIR v_bfi_b32 + v_fma_f32", k_pair_bfi_fma},
+                       {"PAIR v_rcp_f32 + v_fma_f32", k_pair_rcp_fma},
+                       {"PAIR v_lshl_or_b32 + v_fma_f32", k_pair_lshlor_fma},
+                       {"PAIR v_alignbit_b32 + v_max_f32", k_pair_alignbit_max},
+                       {"PAIR v_max3_f32 + v_max_f32", k_pair_max3_max},
+                       {"PAIR v_min3_f32 + v_max_f32", k_pair_min3_max},
+                       {"PAIR v_cmp_lt_f32 sgpr + v_max_f32", k_pair_cmps_max},
+                       {"PAIR v_pk_max_i16 + v_max_f32", k_pair_pkmaxi_max},
+                       {"PAIR v_lshlrev_b32 + v_max_f32", k_pair_shl_max},
+                       {"PAIR v_add_u32 + v_max_f32", k_pair_addu_max},
+                       {"PAIR v_and_b32 + v_max_f32", k_pair_and_max},
+                       {"PAIR v_mov_b32 + v_max_f32", k_pair_mov_max},
+                       {"PAIR v_cvt_f32_f16 + v_max_f32", k_pair_cvth_max},
+                       {"PAIR v_fma_mix_f32 + v_max_f32", k_pair_fmamix_max},
+                       {"PAIR v_mul_f32 + v_max_f32", k_pair_mul_max},
+                       {"PAIR v_bfi_b32 + v_max_f32", k_pair_bfi_max},
+                       {"PAIR v_rcp_f32 + v_max_f32", k_pair_rcp_max},
+                       {"PAIR v_lshl_or_b32 + v_max_f32", k_pair_lshlor_max},
+                       {"PAIR v_alignbit_b32 + v_fma_mix_f32", k_pair_alignbit_fmamix},
+                       {"PAIR v_max_f32 + v_fma_mix_f32", k_pair_max_fmamix},
+                       {"PAIR v_max3_f32 + v_fma_mix_f32", k_pair_max3_fmamix},
+                       {"PAIR v_min3_f32 + v_fma_mix_f32", k_pair_min3_fmamix},
+                       {"PAIR v_cmp_lt_f32 sgpr + v_fma_mix_f32", k_pair_cmps_fmamix},
+                       {"PAIR v_pk_max_i16 + v_fma_mix_f32", k_pair_pkmaxi_fmamix},
+                       {"PAIR v_lshlrev_b32 + v_fma_mix_f32", k_pair_shl_fmamix},
+                       {"PAIR v_add_u32 + v_fma_mix_f32", k_pair_addu_fmamix},
+                       {"PAIR v_and_b32 + v_fma_mix_f32", k_pair_and_fmamix},
+                       {"PAIR v_mov_b32 + v_fma_mix_f32", k_pair_mov_fmamix},
+                       {"PAIR v_cvt_f32_f16 + v_fma_mix_f32", k_pair_cvth_fmamix},
+                       {"PAIR v_mul_f32 + v_fma_mix_f32", k_pair_mul_fmamix},
+                       {"PAIR v_bfi_b32 + v_fma_mix_f32", k_pair_bfi_fmamix},
+                       {"PAIR v_rcp_f32 + v_fma_mix_f32", k_pair_rcp_fmamix},
+                       {"PAIR v_lshl_or_b32 + v_fma_mix_f32", k_pair_lshlor_fmamix}};
     const int iters = 2000;
     printf("%-26s %10s %10s %10s %10s   SIMD cycles per wave-instruction\n", "instruction", "1 w/SIMD", "2 w/SIMD", "4 w/SIMD", "8 w/SIMD");
     for (const Desc& kd : ks) {
