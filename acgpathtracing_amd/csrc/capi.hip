@@ -365,6 +365,10 @@ static int ensure_node_format(pt_ctx* c, int fmt)
         case 1: case 2: case 4: ok = ptd::ensure_qnodes(c->bvh, c->stream, err); break;
         case 6: ok = ptd::ensure_cnodes(c->bvh, c->stream, err); break;
         case 3: return ensure_wide(c);
+        case 10:
+            ok = ptd::ensure_srecs(c->bvh, c->stream, err);
+            if (ok && c->bvh.n_srecs > 32767u) return fail(c, "this kernel variant addresses its shared-plane records with 15-bit child references (scenes up to ~8 000 triangles)");
+            break;
         default: return fail(c, "unknown node format");
     }
     return ok ? 0 : fail(c, err);
@@ -608,7 +612,7 @@ PT_API int pt_set_stream(pt_ctx* c, void* s)
 static ptd::DeviceScene device_scene(pt_ctx* c)
 {
     ptd::DeviceScene sc;
-    sc.nodes = c->bvh.nodes; sc.qnodes = c->bvh.qnodes; sc.cnodes = c->bvh.cnodes; sc.hnodes = c->bvh.hnodes; sc.top = c->bvh.top_nodes; sc.n_top = c->bvh.n_top; sc.hspace = c->bvh.hspace; sc.grid = c->bvh.grid; sc.tris = c->bvh.tris; sc.shade = c->bvh.shade; sc.wrecs = c->bvh.wrecs; sc.mats = c->d_mats;
+    sc.nodes = c->bvh.nodes; sc.qnodes = c->bvh.qnodes; sc.cnodes = c->bvh.cnodes; sc.hnodes = c->bvh.hnodes; sc.top = c->bvh.top_nodes; sc.n_top = c->bvh.n_top; sc.hspace = c->bvh.hspace; sc.grid = c->bvh.grid; sc.tris = c->bvh.tris; sc.shade = c->bvh.shade; sc.wrecs = c->bvh.wrecs; sc.srecs = c->bvh.srecs; sc.sspace = c->bvh.sspace; sc.mats = c->d_mats;
     sc.n_tris = c->bvh.n_tris; sc.n_mats = c->n_mats;
     sc.lights = c->d_lights; sc.n_lights = c->n_lights; sc.light_area = c->light_area;
     return sc;
@@ -1024,7 +1028,8 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
         const int cap_signed = ptd::render_variant_stack_cap(variant);      // > 0: entries in LDS, the rest here; < 0: a sliding window of that many, every slot has a home here
         const uint32_t cap = (uint32_t)(cap_signed < 0 ? -cap_signed : cap_signed);
         if (cap > 0u && c->stack_entries > cap) {
-            const size_t need = (size_t)grid * wpb * 64u * (cap_signed < 0 ? c->stack_entries : c->stack_entries - cap) * sizeof(uint32_t);
+            const size_t need = (size_t)grid * wpb * 64u * (cap_signed < 0 ? c->stack_entries : c->stack_entries - cap) * sizeof(uint32_t)
+                                * (ptd::render_variant_node_format(variant) == 10 ? 2u : 1u);       // the shared-plane kernel's entries are {node, interval}
             if (need > c->stack_ovf_bytes) {
                 CK(c, hipStreamSynchronize(c->stream));
                 if (c->d_stack_ovf) { (void)hipFree(c->d_stack_ovf); c->d_stack_ovf = nullptr; c->stack_ovf_bytes = 0; }

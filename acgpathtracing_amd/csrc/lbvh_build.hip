@@ -681,6 +681,7 @@ void free_lbvh(LbvhResult& r)
     if (r.tris) (void)hipFree(r.tris);
     if (r.shade) (void)hipFree(r.shade);
     if (r.wrecs) (void)hipFree(r.wrecs);
+    if (r.srecs) (void)hipFree(r.srecs);
     r = LbvhResult();
 }
 
@@ -865,6 +866,78 @@ bool build_top_nodes(LbvhResult& r, hipStream_t stream, std::string& err)
     return true;
 }
 
+// --- 11. shared-plane records (NODE_FMT 10; pt_device.h SSpace) ---------------------------------------------------------------
+// From the fp32 nodes: one 16-byte record per inner node and the 48-byte triangle records, in ONE array in which the two children of
+// every node are contiguous (child 0, then child 1; a triangle takes three records).  Record 0 is the root; the children pairs follow in
+// node-index order (PLOC numbers its nodes top-down, so this is close to breadth first).  Three passes over the nodes and one over the
+// triangles; positions from an exclusive scan of the pair sizes.
+__device__ __forceinline__ uint32_t s_child_size(int c, bool single) { return c >= 0 ? 1u : (single ? 0u : 3u); }
+__global__ void k_s_sizes(const BvhNode* __restrict__ nodes, uint32_t n_nodes, bool single_tri, uint32_t* __restrict__ sizes)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const int4 ch = nodes[i].d;
+    // a single-triangle scene has one node whose second child is an empty box over the same triangle: it takes no records
+    sizes[i] = s_child_size(ch.x, false) + s_child_size(ch.y, single_tri);
+}
+__global__ void k_s_place(const BvhNode* __restrict__ nodes, uint32_t n_nodes, const uint32_t* __restrict__ base /* exclusive scan of sizes */,
+                          uint32_t* __restrict__ pos_node, uint32_t* __restrict__ pos_tri)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const int4 ch = nodes[i].d;
+    const uint32_t p0 = 1u + base[i], p1 = p0 + s_child_size(ch.x, false);
+    if (ch.x >= 0) pos_node[ch.x] = p0; else pos_tri[~ch.x] = p0;
+    if (ch.y >= 0) pos_node[ch.y] = p1; else if (~ch.y != ~ch.x || ch.x >= 0) pos_tri[~ch.y] = p1;
+    if (i == 0u) pos_node[0] = 0u;
+}
+// the new plane on one side of one axis: the child whose plane is NOT the parent's owns it (at least one child's is: the parent's box
+// is the union); magnitudes are compared after rounding, so "inherits" means "the same fp16 plane"
+__device__ __forceinline__ uint32_t s_new_plane(float d0, float d1, float scale)
+{
+    // d0 / d1: distance of child 0's / child 1's plane inside the root's plane of this side; the parent's is the smaller of the two
+    const uint32_t m0 = pack_magnitude(d0, scale, false), m1 = pack_magnitude(d1, scale, false);
+    return m0 > m1 ? m0 : (m1 > m0 ? (m1 | 0x8000u) : m0);        // the larger magnitude lies further inside: that child's own plane
+}
+__global__ void k_s_nodes(const BvhNode* __restrict__ nodes, uint32_t n_nodes, const uint32_t* __restrict__ base, const uint32_t* __restrict__ pos_node,
+                          const uint32_t* __restrict__ pos_tri, SSpace sp, uint4* __restrict__ recs)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const BvhNode nd = nodes[i];
+    const float scale = 1.0f / sp.inv_scale;
+    // child 0: lo (a.x a.y a.z) hi (a.w b.x b.y); child 1: lo (b.z b.w c.x) hi (c.y c.z c.w)
+    const float l0[3] = {nd.a.x, nd.a.y, nd.a.z}, h0[3] = {nd.a.w, nd.b.x, nd.b.y}, l1[3] = {nd.b.z, nd.b.w, nd.c.x}, h1[3] = {nd.c.y, nd.c.z, nd.c.w};
+    const float L[3] = {sp.lx, sp.ly, sp.lz}, H[3] = {sp.hx, sp.hy, sp.hz};
+    const bool empty1 = !(l1[0] <= h1[0]);
+    uint32_t w[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (empty1) {
+            // child 0 keeps its own planes; child 1's "box" is empty for every ray: both of its planes as far inside as the format reaches
+            w[k] = pack_magnitude(l0[k] - L[k], scale, false) | (pack_magnitude(H[k] - h0[k], scale, false) << 16);
+            if (k == 0) w[k] = (pack_magnitude(3.0e38f, scale, true)) | (pack_magnitude(3.0e38f, scale, true) << 16);
+        } else {
+            w[k] = s_new_plane(l0[k] - L[k], l1[k] - L[k], scale) | (s_new_plane(H[k] - h0[k], H[k] - h1[k], scale) << 16);
+        }
+    }
+    const int c0 = nd.d.x, c1 = nd.d.y;
+    const uint32_t ref = (1u + base[i]) | (c0 < 0 ? kSLeaf0 : 0u) | (c1 < 0 ? kSLeaf1 : 0u);
+    (void)pos_tri;
+    recs[pos_node[i]] = make_uint4(w[0], w[1], w[2], ref);
+}
+__global__ void k_s_tris(const TriRecord* __restrict__ tris, uint32_t n_tris, const uint32_t* __restrict__ pos_tri, uint4* __restrict__ recs)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_tris) return;
+    const uint4* src = (const uint4*)(tris + s);
+    uint4* dst = recs + pos_tri[s];
+    dst[0] = src[0]; dst[1] = src[1];
+    uint4 r2 = src[2];
+    r2.w = s;                     // the leaf slot (index into DeviceScene::shade): what a hit on this record reports
+    dst[2] = r2;
+}
+
 // ---- node arrays on demand ------------------------------------------------------------------------------------------------
 static bool sync_ok(hipStream_t stream, const char* what, std::string& err)
 {
@@ -944,6 +1017,41 @@ bool ensure_cnodes(LbvhResult& r, hipStream_t stream, std::string& err)
     return sync_ok(stream, "centre nodes", err);
 }
 
+// shared-plane records, on first use by a kernel variant that walks them (NODE_FMT 10)
+bool ensure_srecs(LbvhResult& r, hipStream_t stream, std::string& err)
+{
+    if (r.srecs || r.n_tris == 0) return true;
+    if (!ensure_nodes(r, stream, err)) return false;
+    Scratch sc;
+    const uint32_t n = r.n_tris, n_nodes = r.n_nodes;
+    uint32_t *d_sizes, *d_pos_node, *d_pos_tri;
+    HIPCK(sc.alloc(&d_sizes, ((size_t)n_nodes + 1) * 4));
+    HIPCK(sc.alloc(&d_pos_node, (size_t)n_nodes * 4));
+    HIPCK(sc.alloc(&d_pos_tri, (size_t)n * 4));
+    const uint32_t n_recs = n_nodes + 3u * n;
+    // the root's planes: the scene box, a little outside (magnitudes are measured inward from them and must not be negative); one unit
+    // of magnitude = 1 / 2046 of the longest extent, so that every magnitude is an fp16 value below 2048 (exact integers; finer near the root planes)
+    SSpace sp;
+    float ext = 0.0f;
+    float* L = &sp.lx; float* H = &sp.hx;
+    for (int k = 0; k < 3; k++) {
+        const float e = r.scene_hi[k] - r.scene_lo[k], pad = fmaxf(e, 1e-30f) * 1e-4f + r.pad_abs;
+        L[k] = r.scene_lo[k] - pad; H[k] = r.scene_hi[k] + pad;
+        ext = fmaxf(ext, H[k] - L[k]);
+    }
+    sp.inv_scale = (ext > 0.0f && ext < INFINITY ? ext : 1.0f) / 2046.0f;
+    HIPCK(hipMalloc((void**)&r.srecs, (size_t)n_recs * sizeof(uint4)));
+    const uint32_t nb = (n_nodes + 255) / 256;
+    k_s_sizes<<<nb, 256, 0, stream>>>(r.nodes, n_nodes, n == 1, d_sizes);
+    k_scan<<<1, 1024, 0, stream>>>(d_sizes, n_nodes);
+    k_s_place<<<nb, 256, 0, stream>>>(r.nodes, n_nodes, d_sizes, d_pos_node, d_pos_tri);
+    k_s_nodes<<<nb, 256, 0, stream>>>(r.nodes, n_nodes, d_sizes, d_pos_node, d_pos_tri, sp, r.srecs);
+    k_s_tris<<<(n + 255) / 256, 256, 0, stream>>>(r.tris, n, d_pos_tri, r.srecs);
+    r.n_srecs = n_recs;
+    r.sspace = sp;
+    return sync_ok(stream, "shared-plane records", err);
+}
+
 // (Morton code, original triangle index) of every leaf slot, as the sort saw them: recomputed from the records, HOST outputs
 bool read_morton(const LbvhResult& r, hipStream_t stream, uint32_t* h_codes, uint32_t* h_prims, std::string& err)
 {
@@ -973,6 +1081,7 @@ size_t scene_device_bytes(const LbvhResult& r)
     if (r.tris) b += (size_t)r.n_tris * sizeof(TriRecord);
     if (r.shade) b += (size_t)r.n_tris * sizeof(float4);
     if (r.wrecs) b += (size_t)r.n_wrecs * 48u;
+    if (r.srecs) b += (size_t)r.n_srecs * sizeof(uint4);
     return b;
 }
 

@@ -64,6 +64,22 @@ struct __attribute__((aligned(16))) HNode {
 };
 static_assert(sizeof(HNode) == 32, "hnode size");
 struct HSpace { float cx, cy, cz, inv_scale; };     // world = g * inv_scale + centre; the builder puts the scene's farthest plane at g = 1023
+
+// Shared-plane node (NODE_FMT 10, round 4), 16 B = ONE 16-byte load per visit.  A child box is its parent's box cut by new planes, and
+// because the parent's box is the union of its two children, each of the parent's six planes is inherited by at least one child: the two
+// children together have at most SIX planes the parent does not.  A node stores exactly those — per axis the new plane on the lo side
+// and the new plane on the hi side, each owned by ONE child — and the traversal carries the ray's interval [tn, tf] in the node's own
+// box (which accounts for every inherited plane, bit for bit: same fma, same constants) down to the children and on the stack.
+//   record = { x: lo_new | hi_new << 16,  y: ...,  z: ...,  children }
+// A plane is an fp16 MAGNITUDE measured inward from the root's plane of its own side — lo planes from the root's lo corner, hi planes
+// from its hi corner, both >= 0 and rounded toward 0, i.e. outward —; the SIGN bit says which child owns it (0: child 0, 1: child 1).
+// Child 0 evaluates the six halves as stored, child 1 negated (a free source modifier of v_fma_mix_f32): a plane owned by the other
+// child then has a NEGATIVE magnitude, i.e. lies beyond the root's plane of its side, where it can neither raise tn nor lower tf — it
+// drops out without a select, a mask or a NaN.  12 v_fma_mix_f32 and 3 rotates per visit (the 32-byte HNode: 12 and 6), one gather.
+// children: record index of child 0; child 1 follows it (a triangle is three records: the TriRecord itself); bit 30 / 31: child 0 / 1
+// is a triangle.  Inner nodes and triangles share the one array, every pair of siblings is contiguous.
+struct SSpace { float lx, ly, lz, hx, hy, hz, inv_scale; };      // the root's planes (world) and world units per unit of magnitude
+constexpr uint32_t kSLeaf0 = 1u << 30, kSLeaf1 = 1u << 31, kSBaseMask = (1u << 30) - 1u;
 constexpr uint32_t kTopNodeFlag = 0x40000000u;      // node reference into the breadth-first copy of the tree's top (DeviceScene::top)
 constexpr uint32_t kTopNodesMax = 255u;
 
@@ -91,6 +107,8 @@ struct DeviceScene {
     const TriRecord*   tris;
     const float4*      shade;     // per leaf slot: geometric normal normalize(cross(e1, e2)) (:890) and material id — what closest-hit shading reads
     const uint4*       wrecs;     // four-wide tree: 48-byte records, wide nodes and triangles in one array (wide_bvh.hip)
+    const uint4*       srecs;     // shared-plane tree (NODE_FMT 10): 16-byte records, nodes and triangles in one array; record 0 = the root
+    SSpace             sspace;
     const DevMaterial* mats;
     uint32_t n_tris;
     uint32_t n_mats;
@@ -304,6 +322,62 @@ __device__ __forceinline__ void slab_h9(uint32_t px, uint32_t py, uint32_t pz, c
     const uint32_t ax = rot16(px, __float_as_uint(mul.x)), ay = rot16(py, __float_as_uint(mul.y)), az = rot16(pz, __float_as_uint(mul.z));
     tn = fmaxf(fmaxf(fma_h_lo(ax, mul.x, add.x), fma_h_lo(ay, mul.y, add.y)), fmaxf(fma_h_lo(az, mul.z, add.z), rtmin));
     tf = fminf(fminf(fma_h_hi(ax, mul.x, add.x), fma_h_hi(ay, mul.y, add.y)), fma_h_hi(az, mul.z, add.z)) * kFarWiden;
+}
+
+// ---- the slab test on shared-plane nodes (NODE_FMT 10; SSpace / record layout above) ----
+// builder side: magnitude of a plane at distance `dist` (>= 0, world units) inside the root's plane of its side, rounded toward 0
+// after the same 2^-18 relative guard as pack_planes (product and reciprocal roundings, rotate flags in the multiplier)
+__device__ __forceinline__ uint32_t pack_magnitude(float dist, float scale, bool owner1)
+{
+    float a = fmaxf(dist, 0.0f) * scale;
+    a = a - a * 3.9e-6f;
+    if (!(a < 65504.0f)) a = 65504.0f;                       // (an empty child's "planes": as far inside as the format reaches)
+    return half_bits(__float2half_rz(a)) | (owner1 ? 0x8000u : 0u);
+}
+// Per-ray constants.  With r = 1 / d on an axis, a lo plane of magnitude g sits at t = (L + g s - o) r = g (s r) + (L - o) r and a hi plane at
+// t = (H - g s - o) r = g (-s r) + (H - o) r.  The packed {lo, hi} pair of a node is rotated so that its low half is the plane the ray
+// meets first (rotate amount in the five lowest mantissa bits of the multiplier, as in setup_ray_h9); then, whatever the ray's
+// sign: near = g_low * mm + an, far = g_high * (-mm) + af with mm = |s r|, an / af = the root's near / far plane distances.
+// an, af are also the ray's interval in the root's box: max3 / min3 of them start the traversal.
+__device__ __forceinline__ void setup_ray_s(const f3& ro, const f3& rd, const SSpace& S, f3& mm, f3& an, f3& af)
+{
+    const f3 r = mk(finite_rcp(rd.x), finite_rcp(rd.y), finite_rcp(rd.z));
+    const f3 alo = mk((S.lx - ro.x) * r.x, (S.ly - ro.y) * r.y, (S.lz - ro.z) * r.z), ahi = mk((S.hx - ro.x) * r.x, (S.hy - ro.y) * r.y, (S.hz - ro.z) * r.z);
+    const bool nx = r.x < 0.0f, ny = r.y < 0.0f, nz = r.z < 0.0f;
+    an = mk(nx ? ahi.x : alo.x, ny ? ahi.y : alo.y, nz ? ahi.z : alo.z);
+    af = mk(nx ? alo.x : ahi.x, ny ? alo.y : ahi.y, nz ? alo.z : ahi.z);
+    mm = mk(fabsf(r.x) * S.inv_scale, fabsf(r.y) * S.inv_scale, fabsf(r.z) * S.inv_scale);
+    mm.x = __uint_as_float((__float_as_uint(mm.x) & ~31u) | (nx ? 16u : 0u));
+    mm.y = __uint_as_float((__float_as_uint(mm.y) & ~31u) | (ny ? 16u : 0u));
+    mm.z = __uint_as_float((__float_as_uint(mm.z) & ~31u) | (nz ? 16u : 0u));
+}
+// v_max_f32 / v_min_f32 as they are: fmaxf / fminf on a value the compiler cannot prove canonical (a select, a loop-carried value, an
+// LDS word) first cost a v_max_f32 x, x each — two half-rate instructions per visit for the carried interval, which is never a NaN
+__device__ __forceinline__ float vmax_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmin_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// both children of a record: entry / exit distances, given the ray's interval [tn, tf] in the node's own box
+__device__ __forceinline__ void slab_s(uint32_t px, uint32_t py, uint32_t pz, const f3& mm, const f3& an, const f3& af, float tn, float tf,
+                                       float& n0, float& f0, float& n1, float& f1)
+{
+    const uint32_t ax = rot16(px, __float_as_uint(mm.x)), ay = rot16(py, __float_as_uint(mm.y)), az = rot16(pz, __float_as_uint(mm.z));
+    const half2_t hx = __builtin_bit_cast(half2_t, ax), hy = __builtin_bit_cast(half2_t, ay), hz = __builtin_bit_cast(half2_t, az);
+    n0 = fmaxf(fmaxf(__builtin_fmaf((float)hx.x, mm.x, an.x), __builtin_fmaf((float)hy.x, mm.y, an.y)), vmax_raw(__builtin_fmaf((float)hz.x, mm.z, an.z), tn));
+    f0 = fminf(fminf(__builtin_fmaf((float)hx.y, -mm.x, af.x), __builtin_fmaf((float)hy.y, -mm.y, af.y)), vmin_raw(__builtin_fmaf((float)hz.y, -mm.z, af.z), tf));
+    n1 = fmaxf(fmaxf(__builtin_fmaf(-(float)hx.x, mm.x, an.x), __builtin_fmaf(-(float)hy.x, mm.y, an.y)), vmax_raw(__builtin_fmaf(-(float)hz.x, mm.z, an.z), tn));
+    f1 = fminf(fminf(__builtin_fmaf((float)hx.y, mm.x, af.x), __builtin_fmaf((float)hy.y, mm.y, af.y)), vmin_raw(__builtin_fmaf((float)hz.y, mm.z, af.z), tf));
+}
+// an interval on the traversal stack: two fp16 in one dword, tn rounded down and tf rounded up (both are >= 0: v_cvt_pkrtz rounds toward 0,
+// one unit in the last place is added to tf; 65504 and beyond become +inf)
+__device__ __forceinline__ uint32_t pack_interval(float tn, float tf)
+{
+    typedef __fp16 h2v __attribute__((ext_vector_type(2)));
+    const h2v p = __builtin_amdgcn_cvt_pkrtz(tn, tf);
+    return __builtin_bit_cast(uint32_t, p) + 0x00010000u;
+}
+__device__ __forceinline__ void unpack_interval(uint32_t p, float& tn, float& tf)
+{
+    const half2_t h = __builtin_bit_cast(half2_t, p);
+    tn = (float)h.x; tf = (float)h.y;
 }
 
 // ------------------------------------------------------------ wave votes ----

@@ -247,13 +247,14 @@ k_render_pw(const RenderArgsBox B)
     static_assert(!WINDOW || ((WIN & (WIN - 1)) == 0 && WIN >= 16), "the window wraps by masking and must hold two trips");
     const uint32_t lds_entries = WINDOW ? (uint32_t)WIN + 1u : ((STACK_CAP > 0 && A.stack_entries > (uint32_t)STACK_CAP) ? (uint32_t)STACK_CAP : A.stack_entries);   // WINDOW: entry WIN of a lane's column holds its window base
     const bool deep = WINDOW && A.stack_entries > (uint32_t)WIN;      // wave-uniform: can a stack outgrow the window at all?
+    constexpr uint32_t ENT = NODE_FMT == 10 ? 2u : 1u;      // dwords per stack entry: the shared-plane kernel keeps {node, interval}
     LaneStack st;
-    st.base = lds_dyn + wave * (lds_entries * 64u) + lane;
+    st.base = lds_dyn + wave * (lds_entries * 64u * ENT) + lane;
     // the overflow region of this wave: a wave-uniform base (scalar registers) and, where an entry is touched, a 32-bit
     // offset from the entry number and the lane — a per-lane 64-bit pointer held across the kernel cost two vector registers
     // and, at the 96 of five waves per SIMD, spills whose scratch traffic was the 18 GB of fabric writes of round 2's profile
     uint32_t* const ovf = STACK_CAP != 0
-        ? A.stack_overflow + (size_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (THREADS / 64) + wave)) * 64u * (WINDOW ? A.stack_entries : A.stack_entries - lds_entries) : nullptr;
+        ? A.stack_overflow + (size_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (THREADS / 64) + wave)) * 64u * ENT * (WINDOW ? A.stack_entries : A.stack_entries - lds_entries) : nullptr;
     const auto push = [&](int at, int v) {
         if (WINDOW) st.push(at & (WIN - 1), v);
         else if (STACK_CAP == 0 || at < (int)lds_entries) st.push(at, v);
@@ -264,11 +265,12 @@ k_render_pw(const RenderArgsBox B)
         if (STACK_CAP == 0 || at < (int)lds_entries) return st.pop(at);
         return (int)ovf[(uint32_t)(at - (int)lds_entries) * 64u + lane];
     };
-    LaneStack2 st2;                                   // NODE_FMT 3: the same LDS region as stack_entries / 2 groups
-    st2.base = (uint2*)(lds_dyn + wave * (lds_entries * 64u)) + lane;
+    LaneStack2 st2;                                   // NODE_FMT 3: the same LDS region as stack_entries / 2 groups; NODE_FMT 10: lds_entries 8-byte entries
+    st2.base = (uint2*)(lds_dyn + wave * (lds_entries * 64u * ENT)) + lane;
+    uint2* const ovf2 = (uint2*)ovf;                  // NODE_FMT 10: the overflow region as 8-byte entries
     DeviceScene sc = A.scene;
     if (NODE_FMT == 3) sc.tris = (const TriRecord*)A.scene.wrecs;      // triangles live in the record array
-    const uint2* lds_nodes = (const uint2*)(lds_dyn + (THREADS / 64) * (lds_entries * 64u));
+    const uint2* lds_nodes = (const uint2*)(lds_dyn + (THREADS / 64) * (lds_entries * 64u * ENT));
     if (NODE_FMT == 2) {
         uint4* dst = (uint4*)(lds_dyn + (THREADS / 64) * (lds_entries * 64u));
         const uint4* src = (const uint4*)sc.qnodes;
@@ -276,7 +278,7 @@ k_render_pw(const RenderArgsBox B)
         __syncthreads();
     }
     // LCG skip-ahead table behind the stacks (and behind the LDS-staged nodes of NODE_FMT 2)
-    uint32_t* const lcg_skip = lds_dyn + (THREADS / 64) * (lds_entries * 64u) + (NODE_FMT == 2 ? A.n_lds_nodes * 8u : 0u);
+    uint32_t* const lcg_skip = lds_dyn + (THREADS / 64) * (lds_entries * 64u * ENT) + (NODE_FMT == 2 ? A.n_lds_nodes * 8u : 0u);
     if (threadIdx.x < 32u) { lcg_skip[2u * threadIdx.x] = A.lcg_mul[threadIdx.x]; lcg_skip[2u * threadIdx.x + 1u] = A.lcg_add[threadIdx.x]; }
     const WaveBook book = wave_book(lcg_skip + 64u + wave * kBookDwords, lane);
     // TOPN > 0 (experiment): the first TOPN nodes of the tree, breadth first, staged in LDS behind the books — every ray walks them;
@@ -312,6 +314,9 @@ k_render_pw(const RenderArgsBox B)
     f3 att = mk(1.0f);
     // ray in flight (rinv / gro: reciprocal direction and origin, in grid space for quantised nodes)
     f3 ro = mk(0.0f), rd = mk(0.0f, 0.0f, 1.0f), rinv = mk(1.0f), gro = mk(0.0f);
+    f3 gfar = mk(0.0f);                               // NODE_FMT 10 only: the root's far plane distances (gro: its near plane distances; rinv: |1 / d| / scale)
+    float cur_tn = 0.0f, cur_tf = 0.0f;               // NODE_FMT 10 only: the ray's interval in the box of `node`
+    uint32_t tos_iv = 0u;                             // ... and, packed as two fp16, in the box of the stack's top element
     AxisRot rot = {0u, 0u, 0u};                       // NODE_FMT 8 only
     constexpr float rtmin = 0.01f;      // both ray kinds start at 0.01 (:750-757 and :660-672): a literal, not a register
     float rtmax = 0.0f, best_t = 0.0f;
@@ -379,10 +384,15 @@ k_render_pw(const RenderArgsBox B)
                         keep_metal = !pd.done && !(pd.nxt_org.x == P.x && pd.nxt_org.y == P.y && pd.nxt_org.z == P.z);
                     }
                     ro = P; rd = L;
-                    { const RenderArgs& Rs = late(); setup_ray<NODE_FMT>(ro, rd, Rs.scene.grid, Rs.scene.hspace, rinv, gro); }
+                    if (NODE_FMT == 10) { const RenderArgs& Rs = late(); setup_ray_s(ro, rd, Rs.scene.sspace, rinv, gro, gfar); }
+                    else { const RenderArgs& Rs = late(); setup_ray<NODE_FMT>(ro, rd, Rs.scene.grid, Rs.scene.hspace, rinv, gro); }
                     if (NODE_FMT == 8) rot = axis_rot(rinv);
                     rtmax = Ldist - 0.01f; best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu;
-                    node = root; sp = 0; if (WINDOW && deep) st.push(WIN, 0); cur_list = 0u; shadow_ray = true; shadow_hit = false; started_shadow = true;
+                    node = root; sp = 0; if (WINDOW && deep) { if (NODE_FMT == 10) st2.push(WIN, 0u, 0u); else st.push(WIN, 0); } cur_list = 0u; shadow_ray = true; shadow_hit = false; started_shadow = true;
+                    if (NODE_FMT == 10) {       // the ray's interval in the root's box: the root planes' distances are the per-ray constants themselves
+                        cur_tn = fmaxf(fmaxf(gro.x, gro.y), fmaxf(gro.z, rtmin)); cur_tf = fminf(fminf(gfar.x, gfar.y), fminf(gfar.z, rtmax));
+                        if (!(cur_tn <= cur_tf * kFarWiden)) node = kSentinel;
+                    }
                 } else {
                     segment_done = true;
                 }
@@ -466,10 +476,15 @@ k_render_pw(const RenderArgsBox B)
         if (STATS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); t_newpath += now - t_mark; }
         if (vote(lp.alive) == 0ull) { if (q.shards_left == 0u && q.res_count == 0u && vote(fin_pending) == 0ull) break; else continue; }
         if (start_radiance) {                                         // traceRadiance :750-757
-            { const RenderArgs& Rs = late(); setup_ray<NODE_FMT>(ro, rd, Rs.scene.grid, Rs.scene.hspace, rinv, gro); }
+            if (NODE_FMT == 10) { const RenderArgs& Rs = late(); setup_ray_s(ro, rd, Rs.scene.sspace, rinv, gro, gfar); }
+            else { const RenderArgs& Rs = late(); setup_ray<NODE_FMT>(ro, rd, Rs.scene.grid, Rs.scene.hspace, rinv, gro); }
             if (NODE_FMT == 8) rot = axis_rot(rinv);
             rtmax = 1e16f; best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu;
-            node = root; sp = 0; if (WINDOW && deep) st.push(WIN, 0); cur_list = 0u; shadow_ray = false;
+            node = root; sp = 0; if (WINDOW && deep) { if (NODE_FMT == 10) st2.push(WIN, 0u, 0u); else st.push(WIN, 0); } cur_list = 0u; shadow_ray = false;
+            if (NODE_FMT == 10) {
+                cur_tn = fmaxf(fmaxf(gro.x, gro.y), fmaxf(gro.z, rtmin)); cur_tf = fminf(fminf(gfar.x, gfar.y), fminf(gfar.z, rtmax));
+                if (!(cur_tn <= cur_tf * kFarWiden)) node = kSentinel;
+            }
         }
         n_radiance += (unsigned long long)popc(vote(start_radiance));
 
@@ -519,6 +534,80 @@ k_render_pw(const RenderArgsBox B)
                         node = (nib & 4u) ? ~idx : idx;
                     } else {
                         node = kSentinel;
+                    }
+                }
+                continue;
+            }
+            if constexpr (NODE_FMT == 10) {
+                // ---- shared-plane records: one 16-byte gather per visit, the ray's interval carried down and on the stack ----
+                static_assert(NODE_FMT != 10 || (INNER >= 1 && STACK_CAP <= 0 && TOPN == 0 && !SKIP), "shared-plane kernel: register stack top, whole or windowed LDS stack");
+                constexpr int TRIP = INNER >= 2 ? INNER : 1;
+                const auto push8 = [&](int at, int ref, uint32_t iv) { st2.push(WINDOW ? (at & (WIN - 1)) : at, (uint32_t)ref, iv); };
+                const auto pop8 = [&](int at, int& ref, uint32_t& iv) { const uint2 e = st2.pop(WINDOW ? (at & (WIN - 1)) : at); ref = (int)e.x; iv = e.y; };
+                if (WINDOW && deep) {
+                    static_assert(!WINDOW || WIN >= 2 * TRIP + LEAVES + 3, "window too small: moving entries out and back in would alternate");
+                    int wbase = (int)st2.pop(WIN).x;
+                    for (;;) {
+                        const bool out = act && sp + TRIP > wbase + WIN;
+                        const bool in = act && wbase > 0 && sp - (TRIP + LEAVES) < wbase;
+                        if (vote(out || in) == 0ull) break;
+                        n_moves += 1u;
+                        if (out) {
+#pragma unroll
+                            for (int j = 0; j < 4; j++) ovf2[(uint32_t)(wbase + j) * 64u + lane] = st2.pop((wbase + j) & (WIN - 1));
+                            wbase += 4;
+                        } else if (in) {
+                            wbase -= 4;
+#pragma unroll
+                            for (int j = 0; j < 4; j++) { const uint2 e = ovf2[(uint32_t)(wbase + j) * 64u + lane]; st2.push((wbase + j) & (WIN - 1), e.x, e.y); }
+                        }
+                        if (out || in) st2.push(WIN, (uint32_t)wbase, 0u);
+                    }
+                }
+#pragma unroll
+                for (int visit = 0; visit < TRIP; visit++)
+                if ((uint32_t)node < (uint32_t)kSentinel) {
+                    const uint4 q = *(const uint4*)((const char*)sc.srecs + (size_t)((uint32_t)node << 4));
+                    cur_tf = vmin_raw(cur_tf, best_t * kTieWiden);
+                    float n0, f0, n1, f1;
+                    slab_s(q.x, q.y, q.z, rinv, gro, gfar, cur_tn, cur_tf, n0, f0, n1, f1);
+                    // children: two 16-bit references, bit 15 = triangle (sign-extended: negative, as every leaf reference of this kernel)
+                    const int c0 = (int)(short)(q.w & 0xFFFFu), c1 = (int)q.w >> 16;
+                    const bool h0 = n0 <= f0 * kFarWiden, h1 = n1 <= f1 * kFarWiden;
+                    const bool first0 = n0 <= n1;
+                    const bool pick0 = h0 && (first0 || !h1);
+                    if (h0 && h1) { push8(sp, tos, tos_iv); tos = first0 ? c1 : c0; tos_iv = pack_interval(first0 ? n1 : n0, first0 ? f1 : f0); sp++; }
+                    if (h0 || h1) {
+                        node = pick0 ? c0 : c1; cur_tn = pick0 ? n0 : n1; cur_tf = pick0 ? f0 : f1;
+                    } else {
+                        node = sp ? tos : kSentinel;
+                        unpack_interval(tos_iv, cur_tn, cur_tf);
+                        sp = sp ? sp - 1 : 0;
+                        pop8(sp, tos, tos_iv);
+                    }
+                }
+                const bool at_leaf = node < 0;
+                const unsigned long long lm = vote(at_leaf);
+                if (lm != 0ull && (LEAF_K <= 1 || popc(lm) >= LEAF_K || vote(node >= 0 && node != kSentinel) == 0ull)) {
+#pragma unroll
+                    for (int leaf = 0; leaf < LEAVES; leaf++)
+                    if (node < 0) {
+                        const uint4* tp = (const uint4*)((const char*)sc.srecs + (size_t)(((uint32_t)node & 0x7FFFu) << 4));
+                        const uint4 u0 = tp[0], u1 = tp[1], u2 = tp[2];
+                        const float4 r0 = make_float4(__uint_as_float(u0.x), __uint_as_float(u0.y), __uint_as_float(u0.z), __uint_as_float(u0.w));
+                        const float4 r1 = make_float4(__uint_as_float(u1.x), __uint_as_float(u1.y), __uint_as_float(u1.z), __uint_as_float(u1.w));
+                        float t;
+                        const bool ok = tri_test_lazy(ro, rd, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), mk(r1.z, r1.w, __uint_as_float(u2.x)), rtmin, rtmax, t);
+                        const uint32_t prim = u2.y;
+                        bool stop = false;
+                        if (ok) {
+                            if (shadow_ray) { shadow_hit = true; stop = true; }
+                            else if (t < best_t || (t == best_t && prim < best_prim)) { best_t = t; best_slot = (int)u2.w; best_prim = prim; }
+                        }
+                        node = (stop || sp == 0) ? kSentinel : tos;
+                        unpack_interval(tos_iv, cur_tn, cur_tf);
+                        sp = sp ? sp - 1 : 0;
+                        pop8(sp, tos, tos_iv);
                     }
                 }
                 continue;
@@ -1234,7 +1323,8 @@ static size_t variant_lds(const VariantDesc& d, uint32_t stack_entries, uint32_t
 #endif
     if (d.stack_cap > 0 && stack_entries > (uint32_t)d.stack_cap) stack_entries = (uint32_t)d.stack_cap;
     if (d.stack_cap < 0) stack_entries = (uint32_t)(-d.stack_cap) + 1u;      // sliding window: that many entries, whatever the tree, + the window base
-    size_t lds = (size_t)(d.threads / 64) * (stack_entries * 256u + kBookDwords * 4u) + 256u + (size_t)d.top_n * sizeof(HNode);      // lane stacks, fold bookkeeping, LCG skip-ahead table, staged top of the tree
+    const uint32_t ent = d.node_fmt == 10 ? 2u : 1u;     // the shared-plane kernel's stack entries are 8 bytes
+    size_t lds = (size_t)(d.threads / 64) * (stack_entries * 256u * ent + kBookDwords * 4u) + 256u + (size_t)d.top_n * sizeof(HNode);      // lane stacks, fold bookkeeping, LCG skip-ahead table, staged top of the tree
     if (d.node_fmt == 2) lds += (size_t)n_nodes * sizeof(QNode);
     return lds;
 }
