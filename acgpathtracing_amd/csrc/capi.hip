@@ -365,6 +365,7 @@ static int ensure_node_format(pt_ctx* c, int fmt)
         case 1: case 2: case 4: ok = ptd::ensure_qnodes(c->bvh, c->stream, err); break;
         case 6: ok = ptd::ensure_cnodes(c->bvh, c->stream, err); break;
         case 3: return ensure_wide(c);
+        case 11: ok = ptd::ensure_hcnodes(c->bvh, c->stream, err); break;
         case 10:
             ok = ptd::ensure_srecs(c->bvh, c->stream, err);
             if (ok && c->bvh.n_srecs > 32767u) return fail(c, "this kernel variant addresses its shared-plane records with 15-bit child references (scenes up to ~8 000 triangles)");
@@ -612,7 +613,7 @@ PT_API int pt_set_stream(pt_ctx* c, void* s)
 static ptd::DeviceScene device_scene(pt_ctx* c)
 {
     ptd::DeviceScene sc;
-    sc.nodes = c->bvh.nodes; sc.qnodes = c->bvh.qnodes; sc.cnodes = c->bvh.cnodes; sc.hnodes = c->bvh.hnodes; sc.top = c->bvh.top_nodes; sc.n_top = c->bvh.n_top; sc.hspace = c->bvh.hspace; sc.grid = c->bvh.grid; sc.tris = c->bvh.tris; sc.shade = c->bvh.shade; sc.wrecs = c->bvh.wrecs; sc.srecs = c->bvh.srecs; sc.sspace = c->bvh.sspace; sc.mats = c->d_mats;
+    sc.nodes = c->bvh.nodes; sc.qnodes = c->bvh.qnodes; sc.cnodes = c->bvh.cnodes; sc.hnodes = c->bvh.hnodes; sc.top = c->bvh.top_nodes; sc.n_top = c->bvh.n_top; sc.hspace = c->bvh.hspace; sc.grid = c->bvh.grid; sc.tris = c->bvh.tris; sc.shade = c->bvh.shade; sc.wrecs = c->bvh.wrecs; sc.hcnodes = c->bvh.hcnodes; sc.srecs = c->bvh.srecs; sc.sspace = c->bvh.sspace; sc.mats = c->d_mats;
     sc.n_tris = c->bvh.n_tris; sc.n_mats = c->n_mats;
     sc.lights = c->d_lights; sc.n_lights = c->n_lights; sc.light_area = c->light_area;
     return sc;
@@ -1184,10 +1185,10 @@ PT_API int pt_bench_traversal(pt_ctx* c, const float* rays, size_t n, int repeat
 // in / out sizes per element, in dwords (op 1: in = {seed, count}, out = 2 * count)
 PT_API int pt_selftest(pt_ctx* c, int op, const void* in, size_t n, void* out)
 {
-    //                            0  1  2   3   4   5   6   7   8  9 10 11 12 13 14 15 16 17 18  19  20 .. 29 unused           30 31 32 33 34 35 36 37 38
-    static const int in_dw[39] = {2, 2, 3, 10, 10, 10, 10, 10, 10, 7, 4, 1, 6, 4, 2, 2, 6, 7, 3, 17, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 1, 6, 4, 2, 2, 6, 7, 3},
-                     out_dw[39] = {1, 0, 1, 3, 3, 3, 3, 3, 3, 4, 2, 4, 3, 3, 3, 3, 3, 3, 1, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 3, 3, 3, 3, 3, 3, 1};
-    if (!c || !in || !out || op < 0 || op > 38 || in_dw[op] == 0 || n == 0 || n > (1u << 24)) return fail(c, "pt_selftest: bad argument");
+    //                            0  1  2   3   4   5   6   7   8  9 10 11 12 13 14 15 16 17 18  19  20 .. 29 unused           30 31 32 33 34 35 36 37 38  39
+    static const int in_dw[40] = {2, 2, 3, 10, 10, 10, 10, 10, 10, 7, 4, 1, 6, 4, 2, 2, 6, 7, 3, 17, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 1, 6, 4, 2, 2, 6, 7, 3, 20},
+                     out_dw[40] = {1, 0, 1, 3, 3, 3, 3, 3, 3, 4, 2, 4, 3, 3, 3, 3, 3, 3, 1, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 3, 3, 3, 3, 3, 3, 1, 3};
+    if (!c || !in || !out || op < 0 || op > 39 || in_dw[op] == 0 || n == 0 || n > (1u << 24)) return fail(c, "pt_selftest: bad argument");
     CK(c, hipSetDevice(c->device));
     size_t in_bytes = n * (size_t)in_dw[op] * 4, out_bytes = n * (size_t)out_dw[op] * 4;
     uint32_t launch_n = (uint32_t)n;

@@ -573,6 +573,22 @@ __global__ void k_half_nodes(const BvhNode* __restrict__ nodes, uint32_t n, HSpa
     if ((threadIdx.x & 63) == 0) { atomicAdd(&area[0], before); atomicAdd(&area[1], after); atomicAdd(&area[2], boxes); atomicAdd(&area[3], inflation); }
 }
 
+// --- 8b. fp16 centre / half-extent copy (NODE_FMT 11): child references of inner nodes as byte offsets (index * 32) -------------
+__global__ void k_hc_nodes(const BvhNode* __restrict__ nodes, uint32_t n, HSpace sp, HNode* __restrict__ hn)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const BvhNode nd = nodes[i];
+    const float scale = 1.0f / sp.inv_scale;
+    HNode o;
+    // child 0: lo (a.x a.y a.z) hi (a.w b.x b.y); child 1: lo (b.z b.w c.x) hi (c.y c.z c.w)
+    o.a = make_uint4(pack_centre_half(nd.a.x, nd.a.w, sp.cx, scale), pack_centre_half(nd.a.y, nd.b.x, sp.cy, scale), pack_centre_half(nd.a.z, nd.b.y, sp.cz, scale),
+                     nd.d.x >= 0 ? (uint32_t)nd.d.x << 5 : (uint32_t)nd.d.x);
+    o.b = make_uint4(pack_centre_half(nd.b.z, nd.c.y, sp.cx, scale), pack_centre_half(nd.b.w, nd.c.z, sp.cy, scale), pack_centre_half(nd.c.x, nd.c.w, sp.cz, scale),
+                     nd.d.y >= 0 ? (uint32_t)nd.d.y << 5 : (uint32_t)nd.d.y);
+    hn[i] = o;
+}
+
 // --- 9. the top of the tree, breadth first ---------------------------------------------------------------------------------
 // The first `cap` inner nodes in breadth-first order from the root, as a small array of their own: a child that is in the
 // array too is referenced as kTopNodeFlag | position, every other child as in `hn`.  Render kernels that stage the top of the
@@ -682,6 +698,7 @@ void free_lbvh(LbvhResult& r)
     if (r.shade) (void)hipFree(r.shade);
     if (r.wrecs) (void)hipFree(r.wrecs);
     if (r.srecs) (void)hipFree(r.srecs);
+    if (r.hcnodes) (void)hipFree(r.hcnodes);
     r = LbvhResult();
 }
 
@@ -891,14 +908,6 @@ __global__ void k_s_place(const BvhNode* __restrict__ nodes, uint32_t n_nodes, c
     if (ch.y >= 0) pos_node[ch.y] = p1; else if (~ch.y != ~ch.x || ch.x >= 0) pos_tri[~ch.y] = p1;
     if (i == 0u) pos_node[0] = 0u;
 }
-// the new plane on one side of one axis: the child whose plane is NOT the parent's owns it (at least one child's is: the parent's box
-// is the union); magnitudes are compared after rounding, so "inherits" means "the same fp16 plane"
-__device__ __forceinline__ uint32_t s_new_plane(float d0, float d1, float scale)
-{
-    // d0 / d1: distance of child 0's / child 1's plane inside the root's plane of this side; the parent's is the smaller of the two
-    const uint32_t m0 = pack_magnitude(d0, scale, false), m1 = pack_magnitude(d1, scale, false);
-    return m0 > m1 ? m0 : (m1 > m0 ? (m1 | 0x8000u) : m0);        // the larger magnitude lies further inside: that child's own plane
-}
 __global__ void k_s_nodes(const BvhNode* __restrict__ nodes, uint32_t n_nodes, const uint32_t* __restrict__ base, const uint32_t* __restrict__ pos_node,
                           const uint32_t* __restrict__ pos_tri, SSpace sp, uint4* __restrict__ recs)
 {
@@ -921,8 +930,11 @@ __global__ void k_s_nodes(const BvhNode* __restrict__ nodes, uint32_t n_nodes, c
             w[k] = s_new_plane(l0[k] - L[k], l1[k] - L[k], scale) | (s_new_plane(H[k] - h0[k], H[k] - h1[k], scale) << 16);
         }
     }
+    // children: two 16-bit references, child 0 in the low half: record index in 15 bits, bit 15 = the child is a triangle
+    // (ensure_srecs refuses scenes with more than 32 767 records; larger scenes would take a 32-bit form of this word)
     const int c0 = nd.d.x, c1 = nd.d.y;
-    const uint32_t ref = (1u + base[i]) | (c0 < 0 ? kSLeaf0 : 0u) | (c1 < 0 ? kSLeaf1 : 0u);
+    const uint32_t i0 = 1u + base[i], i1 = i0 + s_child_size(c0, false);
+    const uint32_t ref = (i0 & 0x7FFFu) | (c0 < 0 ? 0x8000u : 0u) | (((i1 & 0x7FFFu) | (c1 < 0 ? 0x8000u : 0u)) << 16);
     (void)pos_tri;
     recs[pos_node[i]] = make_uint4(w[0], w[1], w[2], ref);
 }
@@ -1017,6 +1029,15 @@ bool ensure_cnodes(LbvhResult& r, hipStream_t stream, std::string& err)
     return sync_ok(stream, "centre nodes", err);
 }
 
+bool ensure_hcnodes(LbvhResult& r, hipStream_t stream, std::string& err)
+{
+    if (r.hcnodes || r.n_tris == 0) return true;
+    if (!ensure_nodes(r, stream, err)) return false;
+    HIPCK(hipMalloc((void**)&r.hcnodes, (size_t)r.n_nodes * sizeof(HNode)));
+    k_hc_nodes<<<(r.n_nodes + 255) / 256, 256, 0, stream>>>(r.nodes, r.n_nodes, r.hspace, r.hcnodes);
+    return sync_ok(stream, "fp16 centre / half-extent nodes", err);
+}
+
 // shared-plane records, on first use by a kernel variant that walks them (NODE_FMT 10)
 bool ensure_srecs(LbvhResult& r, hipStream_t stream, std::string& err)
 {
@@ -1049,7 +1070,37 @@ bool ensure_srecs(LbvhResult& r, hipStream_t stream, std::string& err)
     k_s_tris<<<(n + 255) / 256, 256, 0, stream>>>(r.tris, n, d_pos_tri, r.srecs);
     r.n_srecs = n_recs;
     r.sspace = sp;
-    return sync_ok(stream, "shared-plane records", err);
+    if (!sync_ok(stream, "shared-plane records", err)) return false;
+    if (n_recs <= 32767u) {
+        // a walk over what was written, on the host, before any kernel follows these references: every record reached exactly once,
+        // every triangle exactly once, nothing outside the array (the kernels trust the references blindly)
+        std::vector<uint4> h(n_recs);
+        HIPCK(hipMemcpy(h.data(), r.srecs, (size_t)n_recs * sizeof(uint4), hipMemcpyDeviceToHost));
+        std::vector<uint8_t> seen(n_recs, 0);
+        std::vector<uint32_t> todo(1, 0u);
+        uint32_t inner = 0, leaves = 0;
+        bool ok = true;
+        while (!todo.empty() && ok) {
+            const uint32_t at = todo.back(); todo.pop_back();
+            if (at >= n_recs || seen[at]) { ok = false; break; }
+            seen[at] = 1; inner++;
+            const uint32_t w = h[at].w;
+            for (int k = 0; k < 2 && ok; k++) {
+                const uint32_t c = (w >> (16 * k)) & 0xFFFFu, idx = c & 0x7FFFu;
+                if (n == 1 && k == 1) continue;                        // the empty second child of a single-triangle scene
+                if (c & 0x8000u) {
+                    if (idx + 2u >= n_recs || seen[idx] || h[idx + 2].w >= n) ok = false;
+                    else { seen[idx] = seen[idx + 1] = seen[idx + 2] = 1; leaves++; }
+                } else todo.push_back(idx);
+            }
+        }
+        if (!ok || inner != n_nodes || leaves != n) {
+            (void)hipFree(r.srecs); r.srecs = nullptr; r.n_srecs = 0;
+            err = "shared-plane records: inconsistent child references (" + std::to_string(inner) + " nodes, " + std::to_string(leaves) + " triangles reached)";
+            return false;
+        }
+    }
+    return true;
 }
 
 // (Morton code, original triangle index) of every leaf slot, as the sort saw them: recomputed from the records, HOST outputs
@@ -1082,6 +1133,7 @@ size_t scene_device_bytes(const LbvhResult& r)
     if (r.shade) b += (size_t)r.n_tris * sizeof(float4);
     if (r.wrecs) b += (size_t)r.n_wrecs * 48u;
     if (r.srecs) b += (size_t)r.n_srecs * sizeof(uint4);
+    if (r.hcnodes) b += (size_t)r.n_nodes * sizeof(HNode);
     return b;
 }
 

@@ -107,6 +107,7 @@ struct DeviceScene {
     const TriRecord*   tris;
     const float4*      shade;     // per leaf slot: geometric normal normalize(cross(e1, e2)) (:890) and material id — what closest-hit shading reads
     const uint4*       wrecs;     // four-wide tree: 48-byte records, wide nodes and triangles in one array (wide_bvh.hip)
+    const HNode*       hcnodes;   // the fp16 tree with every child box as centre | half extent per axis (NODE_FMT 11), child references as byte offsets
     const uint4*       srecs;     // shared-plane tree (NODE_FMT 10): 16-byte records, nodes and triangles in one array; record 0 = the root
     SSpace             sspace;
     const DevMaterial* mats;
@@ -324,6 +325,38 @@ __device__ __forceinline__ void slab_h9(uint32_t px, uint32_t py, uint32_t pz, c
     tf = fminf(fminf(fma_h_hi(ax, mul.x, add.x), fma_h_hi(ay, mul.y, add.y)), fma_h_hi(az, mul.z, add.z)) * kFarWiden;
 }
 
+// ---- fp16 centre / half-extent nodes (NODE_FMT 11, round 4) ----
+// The HNode layout with {centre, half extent} per axis instead of {lo, hi}: near = c_t - h_t, far = c_t + h_t with c_t = c * (1/d / scale) +
+// (centre - o)/d and h_t = h * |1/d / scale|.  Four instructions per axis and child — two v_fma_mix_f32, one subtract, one add — against the
+// rotated form's two v_fma_mix_f32 and half a v_alignbit_b32; but the subtract and the add are FULL-rate fp32 instructions, which the SIMD executes
+// beside a half-rate neighbour almost for nothing (profiles/r04_ubench_valu.txt: v_max_f32 + v_fma_f32 as a pair 4.7 cycles, alone 4.1 + 2.6),
+// while v_alignbit_b32 is one more half-rate instruction in a loop that is made of them.  No rotate flags in the multipliers either.
+// builder side: c rounded to nearest, h rounded up so that [c - h, c + h] holds the fp32 interval plus the same 2^-18 relative guard as pack_planes
+__device__ __forceinline__ uint32_t pack_centre_half(float lo, float hi, float c0, float scale)
+{
+    if (!(lo <= hi)) return half_bits(__float2half_rn(0.0f)) | (half_bits(__float2half_rn(-1.0f)) << 16);      // empty child: a negative half extent is never hit
+    const float a = (lo - c0) * scale, b = (hi - c0) * scale;
+    const __half hc = __float2half_rn(0.5f * a + 0.5f * b);
+    const float c = __half2float(hc);
+    const float guard = fmaxf(fabsf(a), fabsf(b)) * 3.9e-6f;
+    const float h = fmaxf(b - c, c - a) + guard;
+    return half_bits(hc) | (half_bits(__float2half_ru(h + fabsf(h) * 1e-6f)) << 16);
+}
+__device__ __forceinline__ void setup_ray_hc(const f3& ro, const f3& rd, const HSpace& HS, f3& mul, f3& add)
+{
+    const f3 r = mk(finite_rcp(rd.x), finite_rcp(rd.y), finite_rcp(rd.z));
+    add = mk((HS.cx - ro.x) * r.x, (HS.cy - ro.y) * r.y, (HS.cz - ro.z) * r.z);
+    mul = r * HS.inv_scale;
+}
+__device__ __forceinline__ void slab_hc(uint32_t px, uint32_t py, uint32_t pz, const f3& mul, const f3& add, float rtmin, float& tn, float& tf)
+{
+    const half2_t hx = __builtin_bit_cast(half2_t, px), hy = __builtin_bit_cast(half2_t, py), hz = __builtin_bit_cast(half2_t, pz);
+    const float cx = __builtin_fmaf((float)hx.x, mul.x, add.x), cy = __builtin_fmaf((float)hy.x, mul.y, add.y), cz = __builtin_fmaf((float)hz.x, mul.z, add.z);
+    const float ex = __builtin_fmaf((float)hx.y, fabsf(mul.x), 0.0f), ey = __builtin_fmaf((float)hy.y, fabsf(mul.y), 0.0f), ez = __builtin_fmaf((float)hz.y, fabsf(mul.z), 0.0f);
+    tn = fmaxf(fmaxf(cx - ex, cy - ey), fmaxf(cz - ez, rtmin));
+    tf = fminf(fminf(cx + ex, cy + ey), cz + ez) * kFarWiden;
+}
+
 // ---- the slab test on shared-plane nodes (NODE_FMT 10; SSpace / record layout above) ----
 // builder side: magnitude of a plane at distance `dist` (>= 0, world units) inside the root's plane of its side, rounded toward 0
 // after the same 2^-18 relative guard as pack_planes (product and reciprocal roundings, rotate flags in the multiplier)
@@ -333,6 +366,14 @@ __device__ __forceinline__ uint32_t pack_magnitude(float dist, float scale, bool
     a = a - a * 3.9e-6f;
     if (!(a < 65504.0f)) a = 65504.0f;                       // (an empty child's "planes": as far inside as the format reaches)
     return half_bits(__float2half_rz(a)) | (owner1 ? 0x8000u : 0u);
+}
+// the new plane on one side of one axis: the child whose plane is NOT the parent's owns it (at least one child's is: the parent's box
+// is the union); magnitudes are compared after rounding, so "inherits" means "the same fp16 plane".  d0 / d1: distance of child 0's /
+// child 1's plane inside the root's plane of this side; the parent's is the smaller of the two
+__device__ __forceinline__ uint32_t s_new_plane(float d0, float d1, float scale)
+{
+    const uint32_t m0 = pack_magnitude(d0, scale, false), m1 = pack_magnitude(d1, scale, false);
+    return m0 > m1 ? m0 : (m1 > m0 ? (m1 | 0x8000u) : m0);        // the larger magnitude lies further inside: that child's own plane
 }
 // Per-ray constants.  With r = 1 / d on an axis, a lo plane of magnitude g sits at t = (L + g s - o) r = g (s r) + (L - o) r and a hi plane at
 // t = (H - g s - o) r = g (-s r) + (H - o) r.  The packed {lo, hi} pair of a node is rotated so that its low half is the plane the ray

@@ -175,6 +175,8 @@ __device__ __forceinline__ void setup_ray(const f3& ro, const f3& rd, const QGri
         gro = mk(-(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z));
     } else if (NODE_FMT == 9) {                      // the same with the rotate amounts in the multipliers (pt_device.h)
         setup_ray_h9(ro, rd, HS, rinv, gro);
+    } else if (NODE_FMT == 11) {                     // fp16 centre / half-extent nodes: the plain multiplier and addend
+        setup_ray_hc(ro, rd, HS, rinv, gro);
     } else if (NODE_FMT == 7 || NODE_FMT == 8) {     // t = g * (1/d / scale) + (centre - o)/d, g = the fp16 plane
         const f3 r = mk(finite_rcp(rd.x), finite_rcp(rd.y), finite_rcp(rd.z));
         gro = mk((HS.cx - ro.x) * r.x, (HS.cy - ro.y) * r.y, (HS.cz - ro.z) * r.z);
@@ -716,6 +718,13 @@ k_render_pw(const RenderArgsBox B)
                     c0 = (int)qa.w; c1 = (int)qb.w;
                     slab_h9(qa.x, qa.y, qa.z, rinv, gro, rtmin, n0, f0);
                     slab_h9(qb.x, qb.y, qb.z, rinv, gro, rtmin, n1, f1);
+                } else if (NODE_FMT == 11) {
+                    // fp16 centre / half-extent nodes (pt_device.h): no rotates; child references of inner nodes are byte offsets
+                    const uint4* np = (const uint4*)((const char*)sc.hcnodes + (size_t)(uint32_t)node);
+                    const uint4 qa = np[0], qb = np[1];
+                    c0 = (int)qa.w; c1 = (int)qb.w;
+                    slab_hc(qa.x, qa.y, qa.z, rinv, gro, rtmin, n0, f0);
+                    slab_hc(qb.x, qb.y, qb.z, rinv, gro, rtmin, n1, f1);
                 } else if (NODE_FMT == 6) {
                     // centre / half-extent nodes: near = (c - o)/d - h/|d|, far = (c - o)/d + h/|d|: full-rate arithmetic only,
                     // the |.| is a source modifier

@@ -118,6 +118,38 @@ __global__ void k_selftest(int op, const uint32_t* __restrict__ in, uint32_t n, 
         out[3 * i] = tn <= fminf(tf, r[16]) ? 1u : 0u; fout[3 * i + 1] = tn; fout[3 * i + 2] = tf;
         return;
     }
+    if (op == 39) {
+        // the shared-plane kernel's box test end to end (NODE_FMT 10): in = ray o xyz, d xyz, box lo xyz, hi xyz (fp32, as the builder
+        // holds it), root planes L xyz, H xyz, inv_scale, tmax.  The box is once child 0 and once child 1 of a node whose other child
+        // is the root box itself (so the box owns all six new planes and the sibling inherits all six): s_new_plane / pack_magnitude,
+        // setup_ray_s, the root interval from the per-ray constants, slab_s — what k_render_pw<..., 10, ...> executes — and the
+        // interval's trip over the stack (pack_interval / unpack_interval).  out = accepted as child 0, as child 1, root accepted | sibling accepted << 1
+        const float* r = fin + 20 * i;
+        SSpace sp; sp.lx = r[12]; sp.ly = r[13]; sp.lz = r[14]; sp.hx = r[15]; sp.hy = r[16]; sp.hz = r[17]; sp.inv_scale = r[18];
+        const float scale = 1.0f / sp.inv_scale, tmax = r[19];
+        f3 mm, an, af;
+        setup_ray_s(mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5]), sp, mm, an, af);
+        float tn = fmaxf(fmaxf(an.x, an.y), fmaxf(an.z, 0.01f)), tf = fminf(fminf(af.x, af.y), fminf(af.z, tmax));
+        const bool root_ok = tn <= tf * kFarWiden;
+        { float a, b; unpack_interval(pack_interval(fmaxf(tn, 0.0f), fmaxf(tf, 0.0f)), a, b); if (root_ok) { tn = a; tf = b; } }      // as if it had waited on the stack
+        uint32_t acc[2]; bool sib[2];
+#pragma unroll
+        for (int as1 = 0; as1 < 2; as1++) {
+            uint32_t w[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float dl = r[6 + k] - r[12 + k], dh = r[15 + k] - r[9 + k];
+                w[k] = as1 ? (s_new_plane(0.0f, dl, scale) | (s_new_plane(0.0f, dh, scale) << 16)) : (s_new_plane(dl, 0.0f, scale) | (s_new_plane(dh, 0.0f, scale) << 16));
+            }
+            float n0, f0, n1, f1;
+            slab_s(w[0], w[1], w[2], mm, an, af, tn, tf, n0, f0, n1, f1);
+            const bool a0 = n0 <= f0 * kFarWiden, a1 = n1 <= f1 * kFarWiden;
+            acc[as1] = root_ok && (as1 ? a1 : a0) ? 1u : 0u;
+            sib[as1] = root_ok && (as1 ? a0 : a1);
+        }
+        out[3 * i] = acc[0]; out[3 * i + 1] = acc[1]; out[3 * i + 2] = (root_ok ? 1u : 0u) | (sib[0] ? 2u : 0u) | (sib[1] ? 4u : 0u);
+        return;
+    }
     if (op == 10) {                                  // in: world, width, rank, sample; out: x, y
         const int* r = (const int*)in + 4 * i;
         int x, y;

@@ -290,3 +290,66 @@ def test_gpu_fp16_slab_is_conservative(ctx):
         assert accepted[~wide].mean() < 1e-3, accepted[~wide].mean()
         print("fp16 slab test, planes scaled by %.4f: %.2f %% of the rays that miss the box inflated by 2 %% of the scene are accepted, %.1f %% of all rays"
               % (1.0 / inv_scale, 100 * accepted[~wide].mean(), 100 * accepted.mean()))
+
+
+def test_gpu_shared_plane_slab_is_conservative(ctx):
+    """The shared-plane kernel's box test (pt_selftest op 39; NODE_FMT 10: magnitudes measured inward from the root's planes, the sign
+    bit naming the owning child, the other child's copy mirrored beyond the root plane) on the case generator of the fp16 slab test:
+    no ray that meets the box as it was before the builder's pad is rejected, whether the box is child 0 (magnitudes as stored) or
+    child 1 (negated), after the interval's trip over the stack; the sibling that inherits all six planes is the root box and is
+    accepted exactly when the root is; and it is a test, not a constant."""
+    rng = np.random.default_rng(20261005)
+    n = 1 << 21
+    centre = np.array([100.0, -50.0, 30.0], np.float32)
+    H = np.float32(300.0)
+    coord_max = np.float32(np.abs(centre).max() + H)
+    pad_abs = np.float32(coord_max / np.float32(524288.0))
+    size = (H * np.exp(rng.uniform(np.log(1e-4), 0.0, (n, 3)))).astype(np.float32)
+    flat = rng.random(n) < 0.25
+    size[flat, rng.integers(0, 3, flat.sum())] = 0.0
+    lo0 = (centre - H + rng.random((n, 3), dtype=np.float32) * (2 * H - size)).astype(np.float32)
+    rim = rng.random(n) < 0.25
+    side = rng.integers(0, 2, (n, 3)).astype(bool)
+    lo0 = np.where(rim[:, None] & side, centre + H - size, np.where(rim[:, None], centre - H, lo0)).astype(np.float32)
+    hi0 = (lo0 + size).astype(np.float32)
+    pad = np.maximum(np.float32(1e-5) * np.maximum(np.float32(1.0), np.maximum(np.abs(lo0), np.abs(hi0))), pad_abs).astype(np.float32)
+    lo, hi = (lo0 - pad).astype(np.float32), (hi0 + pad).astype(np.float32)
+    far = rng.random(n) < 0.25
+    o = (centre + (rng.random((n, 3), dtype=np.float32) * 2 - 1) * np.where(far[:, None], 32 * H, H)).astype(np.float32)
+    u = rng.random((n, 3), dtype=np.float32)
+    snap = rng.integers(0, 3, (n, 3))
+    target = np.where(snap == 0, lo0, np.where(snap == 1, hi0, lo0 + u * size)).astype(np.float32)
+    d = (target - o).astype(np.float32)
+    rnd_dir = rng.random(n) < 0.15
+    d[rnd_dir] = rng.normal(size=(int(rnd_dir.sum()), 3)).astype(np.float32)
+    d = (d / np.maximum(np.linalg.norm(d.astype(np.float64), axis=1, keepdims=True), 1e-30)).astype(np.float32)
+    for frac, val in ((0.06, 0.0), (0.02, -0.0), (0.02, 1e-30), (0.02, -1e-38), (0.02, 1e-45)):
+        m = rng.random(n) < frac
+        d[m, rng.integers(0, 3, int(m.sum()))] = np.float32(val)
+    keep = np.abs(d).max(axis=1) > 0
+    d[~keep] = np.array([0.0, 1.0, 0.0], np.float32)
+    tmax = np.where(rng.random(n) < 0.5, np.float32(1e16), (np.linalg.norm((target - o).astype(np.float64), axis=1) * rng.uniform(0.5, 1.5, n)).astype(np.float32)).astype(np.float32)
+    must = _exact_slab(o, d, lo0, hi0, 0.01, tmax)
+    assert must.mean() > 0.3
+    wide = _exact_slab(o, d, lo - np.float32(0.02) * H, hi + np.float32(0.02) * H, 0.01, tmax)
+    assert (~wide).mean() > 0.05
+    # the root's planes as lbvh_build.hip ensure_srecs sets them: the scene box (here: of all the padded boxes), 1e-4 of its extent + pad_abs outside
+    s_lo, s_hi = lo.min(axis=0), hi.max(axis=0)
+    ext = (s_hi - s_lo).astype(np.float32)
+    rp = (np.maximum(ext, np.float32(1e-30)) * np.float32(1e-4) + pad_abs).astype(np.float32)
+    Lr, Hr = (s_lo - rp).astype(np.float32), (s_hi + rp).astype(np.float32)
+    inv_scale = np.float32((Hr - Lr).max() / np.float32(2046.0))
+    rec = np.concatenate([o, d, lo, hi, np.broadcast_to(Lr, (n, 3)), np.broadcast_to(Hr, (n, 3)), np.full((n, 1), inv_scale, np.float32), tmax[:, None]], axis=1).astype(np.float32)
+    assert rec.shape == (n, 20)
+    out = np.zeros((n, 3), np.uint32)
+    run(ctx, 39, np.ascontiguousarray(rec), n, out)
+    for k, name in ((0, "child 0 (magnitudes as stored)"), (1, "child 1 (negated)")):
+        accepted = out[:, k] == 1
+        missed = must & ~accepted
+        assert not missed.any(), "%s: box test rejected %d of %d rays that meet the unpadded box, first: %s" % (name, missed.sum(), must.sum(), rec[np.argmax(missed)])
+        assert accepted[~wide].mean() < 2e-3, accepted[~wide].mean()
+        print("shared-plane slab test, %s: %.2f %% of the rays that miss the box inflated by 2 %% of the scene are accepted, %.1f %% of all rays"
+              % (name, 100 * accepted[~wide].mean(), 100 * accepted.mean()))
+    root_ok = (out[:, 2] & 1) == 1
+    assert np.array_equal((out[:, 2] & 2) != 0, root_ok) and np.array_equal((out[:, 2] & 4) != 0, root_ok), "the sibling that inherits every plane IS the root box"
+    assert not (must & ~root_ok).any()
