@@ -338,7 +338,7 @@ static int ensure_top(pt_ctx* c)
 {
     if (ptd::render_variant_top_nodes(c->variant) == 0) return 0;
     std::string err;
-    if (!ptd::ensure_hnodes(c->bvh, c->stream, err)) return fail(c, err);
+    if (!ptd::ensure_hnodes(c->bvh, c->stream, err)) return fail(c, err);      // (the staged top of the tree is a copy of the {lo, hi} nodes)
     if (!ptd::build_top_nodes(c->bvh, c->stream, err)) return fail(c, err);
     return 0;
 }
@@ -366,10 +366,8 @@ static int ensure_node_format(pt_ctx* c, int fmt)
         case 6: ok = ptd::ensure_cnodes(c->bvh, c->stream, err); break;
         case 3: return ensure_wide(c);
         case 11: ok = ptd::ensure_hcnodes(c->bvh, c->stream, err); break;
-        case 10:
-            ok = ptd::ensure_srecs(c->bvh, c->stream, err);
-            if (ok && c->bvh.n_srecs > 32767u) return fail(c, "this kernel variant addresses its shared-plane records with 15-bit child references (scenes up to ~8 000 triangles)");
-            break;
+        case 10: ok = ptd::ensure_srecs(c->bvh, false, c->stream, err); break;       // 15-bit child references: scenes up to ~8 000 triangles
+        case 12: ok = ptd::ensure_srecs(c->bvh, true, c->stream, err); break;
         default: return fail(c, "unknown node format");
     }
     return ok ? 0 : fail(c, err);
@@ -445,8 +443,9 @@ static int set_scene_one(pt_ctx* c, const float* verts_xyzw, size_t n_verts, con
     if (c->variant_auto) { c->variant = pick_variant(c); if (int rc = size_stack(c)) return rc; }
     {   // one node array per scene: the one the chosen kernel reads (fp16: 32 B per node, fp32: 64 B); the other comes back on first use
         const int fmt = ptd::render_variant_node_format(c->variant);
-        if (fmt == 7 || fmt == 8 || fmt == 9) ptd::release_nodes(c->bvh);
-        else if (fmt == 0 || fmt == 5) ptd::release_hnodes(c->bvh);
+        if (fmt == 11) ptd::keep_one_node_array(c->bvh, 2);
+        else if (fmt == 7 || fmt == 8 || fmt == 9) ptd::keep_one_node_array(c->bvh, 1);
+        else if (fmt == 0 || fmt == 5) ptd::keep_one_node_array(c->bvh, 0);
     }
     if (int rc = ensure_variant_arrays(c)) return rc;
     c->scene_serial++;
@@ -1030,7 +1029,7 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
         const uint32_t cap = (uint32_t)(cap_signed < 0 ? -cap_signed : cap_signed);
         if (cap > 0u && c->stack_entries > cap) {
             const size_t need = (size_t)grid * wpb * 64u * (cap_signed < 0 ? c->stack_entries : c->stack_entries - cap) * sizeof(uint32_t)
-                                * (ptd::render_variant_node_format(variant) == 10 ? 2u : 1u);       // the shared-plane kernel's entries are {node, interval}
+                                * ((ptd::render_variant_node_format(variant) == 10 || ptd::render_variant_node_format(variant) == 12) ? 2u : 1u);       // the shared-plane kernel's entries are {node, interval}
             if (need > c->stack_ovf_bytes) {
                 CK(c, hipStreamSynchronize(c->stream));
                 if (c->d_stack_ovf) { (void)hipFree(c->d_stack_ovf); c->d_stack_ovf = nullptr; c->stack_ovf_bytes = 0; }
@@ -1185,10 +1184,10 @@ PT_API int pt_bench_traversal(pt_ctx* c, const float* rays, size_t n, int repeat
 // in / out sizes per element, in dwords (op 1: in = {seed, count}, out = 2 * count)
 PT_API int pt_selftest(pt_ctx* c, int op, const void* in, size_t n, void* out)
 {
-    //                            0  1  2   3   4   5   6   7   8  9 10 11 12 13 14 15 16 17 18  19  20 .. 29 unused           30 31 32 33 34 35 36 37 38  39
-    static const int in_dw[40] = {2, 2, 3, 10, 10, 10, 10, 10, 10, 7, 4, 1, 6, 4, 2, 2, 6, 7, 3, 17, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 1, 6, 4, 2, 2, 6, 7, 3, 20},
-                     out_dw[40] = {1, 0, 1, 3, 3, 3, 3, 3, 3, 4, 2, 4, 3, 3, 3, 3, 3, 3, 1, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 3, 3, 3, 3, 3, 3, 1, 3};
-    if (!c || !in || !out || op < 0 || op > 39 || in_dw[op] == 0 || n == 0 || n > (1u << 24)) return fail(c, "pt_selftest: bad argument");
+    //                            0  1  2   3   4   5   6   7   8  9 10 11 12 13 14 15 16 17 18  19  20 .. 29 unused           30 31 32 33 34 35 36 37 38  39  40
+    static const int in_dw[41] = {2, 2, 3, 10, 10, 10, 10, 10, 10, 7, 4, 1, 6, 4, 2, 2, 6, 7, 3, 17, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 1, 6, 4, 2, 2, 6, 7, 3, 20, 17},
+                     out_dw[41] = {1, 0, 1, 3, 3, 3, 3, 3, 3, 4, 2, 4, 3, 3, 3, 3, 3, 3, 1, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 3, 3, 3, 3, 3, 3, 1, 3, 3};
+    if (!c || !in || !out || op < 0 || op > 40 || in_dw[op] == 0 || n == 0 || n > (1u << 24)) return fail(c, "pt_selftest: bad argument");
     CK(c, hipSetDevice(c->device));
     size_t in_bytes = n * (size_t)in_dw[op] * 4, out_bytes = n * (size_t)out_dw[op] * 4;
     uint32_t launch_n = (uint32_t)n;

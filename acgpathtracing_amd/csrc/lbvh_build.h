@@ -9,10 +9,10 @@
 namespace ptd {
 
 struct LbvhResult {
-    // A scene keeps ONE of the two node arrays below — the one its render kernel reads; the other is released after the build
-    // (release_nodes / release_hnodes) and comes back, bit for bit, on first use (ensure_nodes / ensure_hnodes).
+    // A scene keeps ONE of the node arrays nodes / hnodes / hcnodes — the one its render kernel reads; the others are released after the
+    // build (keep_one_node_array) and come back, bit for bit, on first use (ensure_nodes / ensure_hnodes / ensure_hcnodes).
     BvhNode*   nodes = nullptr;        // device, n_nodes (fp32 boxes, 64 B)
-    HNode*     hnodes = nullptr;       // device, n_nodes (fp16 boxes, 32 B)
+    HNode*     hnodes = nullptr;       // device, n_nodes (fp16 {lo, hi} boxes, 32 B)
     QNode*     qnodes = nullptr;       // device, n_nodes (16-bit grid boxes, 32 B): experiment formats, on first use (ensure_qnodes)
     BvhNode*   cnodes = nullptr;       // device, n_nodes (centre + half-extent boxes, 64 B): experiment format, on first use (ensure_cnodes)
     float      pad_abs = 0.0f;         // absolute pad of the triangle boxes (record_aabb): 2^-19 of the scene's largest |coordinate|
@@ -27,6 +27,7 @@ struct LbvhResult {
     HNode*     hcnodes = nullptr;      // device, n_nodes: fp16 centre | half-extent boxes, child references as byte offsets (NODE_FMT 11; ensure_hcnodes)
     uint4*     srecs = nullptr;        // device, n_srecs x 16 B: shared-plane nodes + triangles in one array (NODE_FMT 10; ensure_srecs)
     uint32_t   n_srecs = 0;
+    bool       srecs_wide = false;     // child references: one 30-bit index + two flags (NODE_FMT 12) instead of two 15-bit references (NODE_FMT 10)
     SSpace     sspace = {0, 0, 0, 0, 0, 0, 1};
     uint4*     wrecs = nullptr;        // device, n_wrecs x 48 B: four-wide nodes + triangles (wide_bvh.hip)
     uint32_t   n_wrecs = 0, n_wnodes = 0, wide_depth = 0;
@@ -46,8 +47,7 @@ bool build_lbvh(const float* h_verts_xyzw, size_t n_verts, const uint32_t* h_idx
 void free_lbvh(LbvhResult& r);
 
 // One node array per scene: release the one the chosen kernel does not read (no-op when it is the only copy of the topology) ...
-void release_nodes(LbvhResult& r);       // frees the fp32 nodes and the experiment formats derived from them
-void release_hnodes(LbvhResult& r);      // frees the fp16 nodes (and the staged top of the tree)
+void keep_one_node_array(LbvhResult& r, int keep);      // keep: 0 fp32 nodes, 1 fp16 {lo, hi} nodes, 2 fp16 {centre, half extent} nodes; frees the others and what derives from them
 // ... and get any of them back on first use.  fp32 nodes: from the topology in the fp16 nodes + the triangle records, the same bits as
 // the build's own (unions are exact); the others from the fp32 nodes.  Synchronous on return.
 bool ensure_nodes(LbvhResult& r, hipStream_t stream, std::string& err);
@@ -55,7 +55,7 @@ bool ensure_hnodes(LbvhResult& r, hipStream_t stream, std::string& err);
 bool ensure_qnodes(LbvhResult& r, hipStream_t stream, std::string& err);
 bool ensure_cnodes(LbvhResult& r, hipStream_t stream, std::string& err);
 bool ensure_hcnodes(LbvhResult& r, hipStream_t stream, std::string& err);    // fp16 centre / half-extent nodes (NODE_FMT 11), from the fp32 nodes
-bool ensure_srecs(LbvhResult& r, hipStream_t stream, std::string& err);      // shared-plane records (NODE_FMT 10), from the fp32 nodes
+bool ensure_srecs(LbvhResult& r, bool wide_refs, hipStream_t stream, std::string& err);      // shared-plane records (NODE_FMT 10), from the fp32 nodes
 // (Morton code, original triangle index) per leaf slot in sorted order, recomputed from the records (the build keeps no copy of its sort keys)
 bool read_morton(const LbvhResult& r, hipStream_t stream, uint32_t* h_codes, uint32_t* h_prims, std::string& err);
 // bytes of device memory the scene's arrays hold right now

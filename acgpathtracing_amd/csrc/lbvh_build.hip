@@ -616,16 +616,18 @@ __global__ void k_top_nodes(const HNode* __restrict__ hn, HNode* __restrict__ to
 // experiment formats derived from them) gets them back from the topology in the fp16 nodes and the triangle records: leaf boxes by
 // record_aabb — the very function the build used — and unions bottom-up, which are exact and order-independent: the same bits
 // as the build's own array.
-__global__ void k_parents_of(const HNode* __restrict__ hn, uint32_t n_nodes, int* __restrict__ node_parent, int* __restrict__ leaf_parent)
+// (shift: 0 for the child references of HNode, 5 for those of the centre / half-extent copy, whose inner references are byte offsets)
+__device__ __forceinline__ int h_child(uint32_t w, int shift) { const int c = (int)w; return c >= 0 ? c >> shift : c; }
+__global__ void k_parents_of(const HNode* __restrict__ hn, int shift, uint32_t n_nodes, int* __restrict__ node_parent, int* __restrict__ leaf_parent)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
-    const int c0 = (int)hn[i].a.w, c1 = (int)hn[i].b.w;
+    const int c0 = h_child(hn[i].a.w, shift), c1 = h_child(hn[i].b.w, shift);
     if (c0 >= 0) node_parent[c0] = (int)i; else leaf_parent[~c0] = (int)i;
     if (c1 >= 0) node_parent[c1] = (int)i; else leaf_parent[~c1] = (int)i;
     if (i == 0u) node_parent[0] = -1;
 }
-__global__ void k_refit_records(int n, const TriRecord* __restrict__ tris, float pad_abs, const HNode* __restrict__ hn,
+__global__ void k_refit_records(int n, const TriRecord* __restrict__ tris, float pad_abs, const HNode* __restrict__ hn, int shift,
                                 const int* __restrict__ node_parent, const int* __restrict__ leaf_parent, uint32_t* __restrict__ visit,
                                 float4* __restrict__ node_lo, float4* __restrict__ node_hi, BvhNode* __restrict__ nodes)
 {
@@ -635,7 +637,7 @@ __global__ void k_refit_records(int n, const TriRecord* __restrict__ tris, float
     while (cur >= 0) {
         const uint32_t prev = __hip_atomic_fetch_add(&visit[cur], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);      // as k_refit: the second arrival proceeds
         if (prev == 0) return;
-        const int c0 = (int)hn[cur].a.w, c1 = (int)hn[cur].b.w;
+        const int c0 = h_child(hn[cur].a.w, shift), c1 = h_child(hn[cur].b.w, shift);
         float l0[3], h0[3], l1[3], h1[3];
         if (c0 < 0) record_aabb(tris[~c0], pad_abs, l0, h0);
         else { const float4 a = node_lo[c0], b = node_hi[c0]; l0[0] = a.x; l0[1] = a.y; l0[2] = a.z; h0[0] = b.x; h0[1] = b.y; h0[2] = b.z; }
@@ -738,7 +740,7 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
     HIPCK(sc.alloc(&d_nparent, (size_t)n_nodes * 4));
     HIPCK(sc.alloc(&d_lparent, (size_t)n * 4));
     // what a scene keeps: the fp32 nodes (the build's own output), their fp16 copy, the triangle and shading records.  The caller
-    // releases the node array its kernel does not read (release_nodes / release_hnodes); either comes back on first use
+    // releases the node arrays its kernel does not read (keep_one_node_array); any of them comes back on first use
     // (ensure_nodes / ensure_hnodes), and so do the experiment formats (ensure_qnodes, ensure_cnodes).
     HIPCK(hipMalloc((void**)&out.nodes, (size_t)n_nodes * sizeof(BvhNode)));
     HIPCK(hipMalloc((void**)&out.hnodes, (size_t)n_nodes * sizeof(HNode)));
@@ -834,6 +836,10 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
         HIPCK(hipGetLastError());
         HIPCK(hipMemcpyAsync(h_area, d_area, 16, hipMemcpyDeviceToHost, stream));
         HIPCK(hipStreamSynchronize(stream));
+        HIPCK(hipMalloc((void**)&out.hcnodes, (size_t)n_nodes * sizeof(HNode)));
+        k_hc_nodes<<<(n_nodes + 255) / 256, 256, 0, stream>>>(out.nodes, n_nodes, sp, out.hcnodes);
+        HIPCK(hipGetLastError());
+        HIPCK(hipStreamSynchronize(stream));
         out.hspace = sp;
         out.half_area_ratio = h_area[0] > 0.0f ? h_area[1] / h_area[0] : 1.0f;
         out.half_box_inflation = h_area[2] > 0.0f ? h_area[3] / h_area[2] : 1.0f;
@@ -909,7 +915,7 @@ __global__ void k_s_place(const BvhNode* __restrict__ nodes, uint32_t n_nodes, c
     if (i == 0u) pos_node[0] = 0u;
 }
 __global__ void k_s_nodes(const BvhNode* __restrict__ nodes, uint32_t n_nodes, const uint32_t* __restrict__ base, const uint32_t* __restrict__ pos_node,
-                          const uint32_t* __restrict__ pos_tri, SSpace sp, uint4* __restrict__ recs)
+                          const uint32_t* __restrict__ pos_tri, SSpace sp, bool wide_refs, uint4* __restrict__ recs)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
@@ -934,7 +940,10 @@ __global__ void k_s_nodes(const BvhNode* __restrict__ nodes, uint32_t n_nodes, c
     // (ensure_srecs refuses scenes with more than 32 767 records; larger scenes would take a 32-bit form of this word)
     const int c0 = nd.d.x, c1 = nd.d.y;
     const uint32_t i0 = 1u + base[i], i1 = i0 + s_child_size(c0, false);
-    const uint32_t ref = (i0 & 0x7FFFu) | (c0 < 0 ? 0x8000u : 0u) | (((i1 & 0x7FFFu) | (c1 < 0 ? 0x8000u : 0u)) << 16);
+    // ... or, for larger scenes (NODE_FMT 12), one 30-bit index: child 0's; child 1 follows it (one record further, three if child 0 is a
+    // triangle); bit 31 / 30: child 0 / child 1 is a triangle (pt_device.h kSLeaf0 / kSLeaf1)
+    const uint32_t ref = wide_refs ? (i0 | (c0 < 0 ? kSLeaf0 : 0u) | (c1 < 0 ? kSLeaf1 : 0u))
+                                   : ((i0 & 0x7FFFu) | (c0 < 0 ? 0x8000u : 0u) | (((i1 & 0x7FFFu) | (c1 < 0 ? 0x8000u : 0u)) << 16));
     (void)pos_tri;
     recs[pos_node[i]] = make_uint4(w[0], w[1], w[2], ref);
 }
@@ -959,25 +968,29 @@ static bool sync_ok(hipStream_t stream, const char* what, std::string& err)
     return true;
 }
 
-void release_nodes(LbvhResult& r)
+void keep_one_node_array(LbvhResult& r, int keep)
 {
-    if (!r.hnodes) return;                  // the only copy of the topology: stays
-    if (r.nodes) { (void)hipFree(r.nodes); r.nodes = nullptr; }
-    if (r.qnodes) { (void)hipFree(r.qnodes); r.qnodes = nullptr; }
-    if (r.cnodes) { (void)hipFree(r.cnodes); r.cnodes = nullptr; }
-}
-
-void release_hnodes(LbvhResult& r)
-{
-    if (!r.nodes) return;
-    if (r.hnodes) { (void)hipFree(r.hnodes); r.hnodes = nullptr; }
-    if (r.top_nodes) { (void)hipFree(r.top_nodes); r.top_nodes = nullptr; r.n_top = 0; }
+    // keep: 0 the fp32 nodes, 1 the fp16 {lo, hi} nodes, 2 the fp16 {centre, half extent} nodes; never the last copy of the topology
+    const bool have = keep == 0 ? r.nodes != nullptr : (keep == 1 ? r.hnodes != nullptr : r.hcnodes != nullptr);
+    if (!have) return;
+    if (keep != 0) {
+        if (r.nodes) { (void)hipFree(r.nodes); r.nodes = nullptr; }
+        if (r.qnodes) { (void)hipFree(r.qnodes); r.qnodes = nullptr; }
+        if (r.cnodes) { (void)hipFree(r.cnodes); r.cnodes = nullptr; }
+    }
+    if (keep != 1) {
+        if (r.hnodes) { (void)hipFree(r.hnodes); r.hnodes = nullptr; }
+        if (r.top_nodes) { (void)hipFree(r.top_nodes); r.top_nodes = nullptr; r.n_top = 0; }
+    }
+    if (keep != 2 && r.hcnodes) { (void)hipFree(r.hcnodes); r.hcnodes = nullptr; }
 }
 
 bool ensure_nodes(LbvhResult& r, hipStream_t stream, std::string& err)
 {
     if (r.nodes || r.n_tris == 0) return true;
-    if (!r.hnodes || !r.tris) { err = "fp32 nodes: neither node array is present"; return false; }
+    const HNode* topo = r.hnodes ? r.hnodes : r.hcnodes;       // either fp16 array holds the topology
+    const int shift = r.hnodes ? 0 : 5;
+    if (!topo || !r.tris) { err = "fp32 nodes: no node array is present"; return false; }
     Scratch sc;
     const uint32_t n = r.n_tris, n_nodes = r.n_nodes;
     HIPCK(hipMalloc((void**)&r.nodes, (size_t)n_nodes * sizeof(BvhNode)));
@@ -991,8 +1004,8 @@ bool ensure_nodes(LbvhResult& r, hipStream_t stream, std::string& err)
         HIPCK(sc.alloc(&d_lo, (size_t)n_nodes * 16));
         HIPCK(sc.alloc(&d_hi, (size_t)n_nodes * 16));
         HIPCK(hipMemsetAsync(d_visit, 0, (size_t)n_nodes * 4, stream));
-        k_parents_of<<<(n_nodes + 255) / 256, 256, 0, stream>>>(r.hnodes, n_nodes, d_np, d_lp);
-        k_refit_records<<<(n + 255) / 256, 256, 0, stream>>>((int)n, r.tris, r.pad_abs, r.hnodes, d_np, d_lp, d_visit, d_lo, d_hi, r.nodes);
+        k_parents_of<<<(n_nodes + 255) / 256, 256, 0, stream>>>(topo, shift, n_nodes, d_np, d_lp);
+        k_refit_records<<<(n + 255) / 256, 256, 0, stream>>>((int)n, r.tris, r.pad_abs, topo, shift, d_np, d_lp, d_visit, d_lo, d_hi, r.nodes);
     }
     return sync_ok(stream, "fp32 nodes", err);
 }
@@ -1000,7 +1013,7 @@ bool ensure_nodes(LbvhResult& r, hipStream_t stream, std::string& err)
 bool ensure_hnodes(LbvhResult& r, hipStream_t stream, std::string& err)
 {
     if (r.hnodes || r.n_tris == 0) return true;
-    if (!r.nodes) { err = "fp16 nodes: neither node array is present"; return false; }
+    if (!ensure_nodes(r, stream, err)) return false;
     Scratch sc;
     float* d_area;
     HIPCK(sc.alloc(&d_area, 16));
@@ -1039,8 +1052,9 @@ bool ensure_hcnodes(LbvhResult& r, hipStream_t stream, std::string& err)
 }
 
 // shared-plane records, on first use by a kernel variant that walks them (NODE_FMT 10)
-bool ensure_srecs(LbvhResult& r, hipStream_t stream, std::string& err)
+bool ensure_srecs(LbvhResult& r, bool wide_refs, hipStream_t stream, std::string& err)
 {
+    if (r.srecs && r.srecs_wide != wide_refs) { (void)hipFree(r.srecs); r.srecs = nullptr; r.n_srecs = 0; }
     if (r.srecs || r.n_tris == 0) return true;
     if (!ensure_nodes(r, stream, err)) return false;
     Scratch sc;
@@ -1050,6 +1064,7 @@ bool ensure_srecs(LbvhResult& r, hipStream_t stream, std::string& err)
     HIPCK(sc.alloc(&d_pos_node, (size_t)n_nodes * 4));
     HIPCK(sc.alloc(&d_pos_tri, (size_t)n * 4));
     const uint32_t n_recs = n_nodes + 3u * n;
+    if ((uint64_t)n_nodes + 3ull * n >= (1ull << 28)) { err = "shared-plane records: the kernels address them with 32-bit byte offsets (2^28 records)"; return false; }
     // the root's planes: the scene box, a little outside (magnitudes are measured inward from them and must not be negative); one unit
     // of magnitude = 1 / 2046 of the longest extent, so that every magnitude is an fp16 value below 2048 (exact integers; finer near the root planes)
     SSpace sp;
@@ -1066,12 +1081,14 @@ bool ensure_srecs(LbvhResult& r, hipStream_t stream, std::string& err)
     k_s_sizes<<<nb, 256, 0, stream>>>(r.nodes, n_nodes, n == 1, d_sizes);
     k_scan<<<1, 1024, 0, stream>>>(d_sizes, n_nodes);
     k_s_place<<<nb, 256, 0, stream>>>(r.nodes, n_nodes, d_sizes, d_pos_node, d_pos_tri);
-    k_s_nodes<<<nb, 256, 0, stream>>>(r.nodes, n_nodes, d_sizes, d_pos_node, d_pos_tri, sp, r.srecs);
+    k_s_nodes<<<nb, 256, 0, stream>>>(r.nodes, n_nodes, d_sizes, d_pos_node, d_pos_tri, sp, wide_refs, r.srecs);
     k_s_tris<<<(n + 255) / 256, 256, 0, stream>>>(r.tris, n, d_pos_tri, r.srecs);
     r.n_srecs = n_recs;
     r.sspace = sp;
+    r.srecs_wide = wide_refs;
     if (!sync_ok(stream, "shared-plane records", err)) return false;
-    if (n_recs <= 32767u) {
+    if (!wide_refs && n_recs > 32767u) { err = "shared-plane records with 15-bit child references: more than 32 767 records"; return false; }
+    if (n_recs <= (8u << 20)) {
         // a walk over what was written, on the host, before any kernel follows these references: every record reached exactly once,
         // every triangle exactly once, nothing outside the array (the kernels trust the references blindly)
         std::vector<uint4> h(n_recs);
@@ -1086,9 +1103,11 @@ bool ensure_srecs(LbvhResult& r, hipStream_t stream, std::string& err)
             seen[at] = 1; inner++;
             const uint32_t w = h[at].w;
             for (int k = 0; k < 2 && ok; k++) {
-                const uint32_t c = (w >> (16 * k)) & 0xFFFFu, idx = c & 0x7FFFu;
+                uint32_t idx; bool is_leaf;
+                if (wide_refs) { const bool l0 = (w & kSLeaf0) != 0; idx = (w & kSBaseMask) + (k ? (l0 ? 3u : 1u) : 0u); is_leaf = (w & (k ? kSLeaf1 : kSLeaf0)) != 0; }
+                else { const uint32_t c = (w >> (16 * k)) & 0xFFFFu; idx = c & 0x7FFFu; is_leaf = (c & 0x8000u) != 0; }
                 if (n == 1 && k == 1) continue;                        // the empty second child of a single-triangle scene
-                if (c & 0x8000u) {
+                if (is_leaf) {
                     if (idx + 2u >= n_recs || seen[idx] || h[idx + 2].w >= n) ok = false;
                     else { seen[idx] = seen[idx + 1] = seen[idx + 2] = 1; leaves++; }
                 } else todo.push_back(idx);

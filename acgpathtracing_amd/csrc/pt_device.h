@@ -79,7 +79,7 @@ struct HSpace { float cx, cy, cz, inv_scale; };     // world = g * inv_scale + c
 // children: record index of child 0; child 1 follows it (a triangle is three records: the TriRecord itself); bit 30 / 31: child 0 / 1
 // is a triangle.  Inner nodes and triangles share the one array, every pair of siblings is contiguous.
 struct SSpace { float lx, ly, lz, hx, hy, hz, inv_scale; };      // the root's planes (world) and world units per unit of magnitude
-constexpr uint32_t kSLeaf0 = 1u << 30, kSLeaf1 = 1u << 31, kSBaseMask = (1u << 30) - 1u;
+constexpr uint32_t kSLeaf0 = 1u << 31, kSLeaf1 = 1u << 30, kSBaseMask = (1u << 30) - 1u;
 constexpr uint32_t kTopNodeFlag = 0x40000000u;      // node reference into the breadth-first copy of the tree's top (DeviceScene::top)
 constexpr uint32_t kTopNodesMax = 255u;
 

@@ -94,7 +94,7 @@ int render_variant_has_fast_math(int variant);   // 0: the variant exists with I
 int render_variant_threads(int variant);
 int render_variant_top_nodes(int variant);      // > 0: the variant stages that many nodes of the tree's top in LDS (experiments)
 int render_variant_stack_cap(int variant);      // 0 = the whole stack in LDS
-int render_variant_node_format(int variant);   // 0 fp32 two-child; 7 / 8 / 9 fp16 two-child (min-max / rotated / rotated, flags in the multipliers); experiments: 1/2/4 16-bit grid, 3 four-wide 8-bit
+int render_variant_node_format(int variant);   // 0 fp32 two-child; 11 fp16 two-child as centre / half extent (the default); 7 / 8 / 9 fp16 two-child {lo, hi} (min-max / rotated / rotated, flags in the multipliers); experiments: 1/2/4 16-bit grid, 3 four-wide 8-bit, 10 / 12 shared-plane records
 hipError_t render_occupancy(int variant, int math, uint32_t stack_entries, uint32_t n_nodes, int* blocks_per_cu);
 hipError_t launch_render(int variant, int math, const RenderArgs& args, uint32_t grid_blocks, hipStream_t stream);
 hipError_t launch_finalize(const RenderArgs& args, hipStream_t stream);

@@ -207,7 +207,10 @@ __device__ __forceinline__ void setup_ray(const f3& ro, const f3& rd, const QGri
 //           8 = the same nodes; each packed {lo, hi} pair is rotated by 0 or 16 bits first (v_alignbit_b32, per ray and axis),
 //               so the low half is the near plane: 6 rotates replace 12 min / max; three registers of rotate amounts
 //           9 = the same, with the rotate amount in the five lowest mantissa bits of the plane multiplier (setup_ray): no
-//               register for it — the default
+//               register for it — the default of rounds 2-3
+//          11 = the same 32-byte nodes holding {centre, half extent} per axis: near / far = c_t -+ h_t by a full-rate subtract / add, no
+//               rotates, child references of inner nodes as byte offsets (round 4: -2 % on every configuration, same bits) — the default
+//          10 / 12 = shared-plane records (experiments): 16-byte nodes, one gather per visit, the ray's interval carried on the stack
 //           5 = the fp32 nodes, slab test as subtract + multiply per plane
 //           4 = 16-bit grid nodes with the fma form
 //           1 = 16-bit grid boxes, 32-byte nodes in global memory (2 loads per visit)
@@ -249,7 +252,8 @@ k_render_pw(const RenderArgsBox B)
     static_assert(!WINDOW || ((WIN & (WIN - 1)) == 0 && WIN >= 16), "the window wraps by masking and must hold two trips");
     const uint32_t lds_entries = WINDOW ? (uint32_t)WIN + 1u : ((STACK_CAP > 0 && A.stack_entries > (uint32_t)STACK_CAP) ? (uint32_t)STACK_CAP : A.stack_entries);   // WINDOW: entry WIN of a lane's column holds its window base
     const bool deep = WINDOW && A.stack_entries > (uint32_t)WIN;      // wave-uniform: can a stack outgrow the window at all?
-    constexpr uint32_t ENT = NODE_FMT == 10 ? 2u : 1u;      // dwords per stack entry: the shared-plane kernel keeps {node, interval}
+    constexpr bool SHARED = NODE_FMT == 10 || NODE_FMT == 12;     // shared-plane records, 15-bit / 30-bit child references
+    constexpr uint32_t ENT = SHARED ? 2u : 1u;      // dwords per stack entry: the shared-plane kernel keeps {node, interval}
     LaneStack st;
     st.base = lds_dyn + wave * (lds_entries * 64u * ENT) + lane;
     // the overflow region of this wave: a wave-uniform base (scalar registers) and, where an entry is touched, a 32-bit
@@ -386,12 +390,12 @@ k_render_pw(const RenderArgsBox B)
                         keep_metal = !pd.done && !(pd.nxt_org.x == P.x && pd.nxt_org.y == P.y && pd.nxt_org.z == P.z);
                     }
                     ro = P; rd = L;
-                    if (NODE_FMT == 10) { const RenderArgs& Rs = late(); setup_ray_s(ro, rd, Rs.scene.sspace, rinv, gro, gfar); }
+                    if (SHARED) { const RenderArgs& Rs = late(); setup_ray_s(ro, rd, Rs.scene.sspace, rinv, gro, gfar); }
                     else { const RenderArgs& Rs = late(); setup_ray<NODE_FMT>(ro, rd, Rs.scene.grid, Rs.scene.hspace, rinv, gro); }
                     if (NODE_FMT == 8) rot = axis_rot(rinv);
                     rtmax = Ldist - 0.01f; best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu;
-                    node = root; sp = 0; if (WINDOW && deep) { if (NODE_FMT == 10) st2.push(WIN, 0u, 0u); else st.push(WIN, 0); } cur_list = 0u; shadow_ray = true; shadow_hit = false; started_shadow = true;
-                    if (NODE_FMT == 10) {       // the ray's interval in the root's box: the root planes' distances are the per-ray constants themselves
+                    node = root; sp = 0; if (WINDOW && deep) { if (SHARED) st2.push(WIN, 0u, 0u); else st.push(WIN, 0); } cur_list = 0u; shadow_ray = true; shadow_hit = false; started_shadow = true;
+                    if (SHARED) {       // the ray's interval in the root's box: the root planes' distances are the per-ray constants themselves
                         cur_tn = fmaxf(fmaxf(gro.x, gro.y), fmaxf(gro.z, rtmin)); cur_tf = fminf(fminf(gfar.x, gfar.y), fminf(gfar.z, rtmax));
                         if (!(cur_tn <= cur_tf * kFarWiden)) node = kSentinel;
                     }
@@ -478,12 +482,12 @@ k_render_pw(const RenderArgsBox B)
         if (STATS) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); t_newpath += now - t_mark; }
         if (vote(lp.alive) == 0ull) { if (q.shards_left == 0u && q.res_count == 0u && vote(fin_pending) == 0ull) break; else continue; }
         if (start_radiance) {                                         // traceRadiance :750-757
-            if (NODE_FMT == 10) { const RenderArgs& Rs = late(); setup_ray_s(ro, rd, Rs.scene.sspace, rinv, gro, gfar); }
+            if (SHARED) { const RenderArgs& Rs = late(); setup_ray_s(ro, rd, Rs.scene.sspace, rinv, gro, gfar); }
             else { const RenderArgs& Rs = late(); setup_ray<NODE_FMT>(ro, rd, Rs.scene.grid, Rs.scene.hspace, rinv, gro); }
             if (NODE_FMT == 8) rot = axis_rot(rinv);
             rtmax = 1e16f; best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu;
-            node = root; sp = 0; if (WINDOW && deep) { if (NODE_FMT == 10) st2.push(WIN, 0u, 0u); else st.push(WIN, 0); } cur_list = 0u; shadow_ray = false;
-            if (NODE_FMT == 10) {
+            node = root; sp = 0; if (WINDOW && deep) { if (SHARED) st2.push(WIN, 0u, 0u); else st.push(WIN, 0); } cur_list = 0u; shadow_ray = false;
+            if (SHARED) {
                 cur_tn = fmaxf(fmaxf(gro.x, gro.y), fmaxf(gro.z, rtmin)); cur_tf = fminf(fminf(gfar.x, gfar.y), fminf(gfar.z, rtmax));
                 if (!(cur_tn <= cur_tf * kFarWiden)) node = kSentinel;
             }
@@ -540,9 +544,9 @@ k_render_pw(const RenderArgsBox B)
                 }
                 continue;
             }
-            if constexpr (NODE_FMT == 10) {
+            if constexpr (SHARED) {
                 // ---- shared-plane records: one 16-byte gather per visit, the ray's interval carried down and on the stack ----
-                static_assert(NODE_FMT != 10 || (INNER >= 1 && STACK_CAP <= 0 && TOPN == 0 && !SKIP), "shared-plane kernel: register stack top, whole or windowed LDS stack");
+                static_assert(!SHARED || (INNER >= 1 && STACK_CAP <= 0 && TOPN == 0 && !SKIP), "shared-plane kernel: register stack top, whole or windowed LDS stack");
                 constexpr int TRIP = INNER >= 2 ? INNER : 1;
                 const auto push8 = [&](int at, int ref, uint32_t iv) { st2.push(WINDOW ? (at & (WIN - 1)) : at, (uint32_t)ref, iv); };
                 const auto pop8 = [&](int at, int& ref, uint32_t& iv) { const uint2 e = st2.pop(WINDOW ? (at & (WIN - 1)) : at); ref = (int)e.x; iv = e.y; };
@@ -574,7 +578,13 @@ k_render_pw(const RenderArgsBox B)
                     float n0, f0, n1, f1;
                     slab_s(q.x, q.y, q.z, rinv, gro, gfar, cur_tn, cur_tf, n0, f0, n1, f1);
                     // children: two 16-bit references, bit 15 = triangle (sign-extended: negative, as every leaf reference of this kernel)
-                    const int c0 = (int)(short)(q.w & 0xFFFFu), c1 = (int)q.w >> 16;
+                    int c0, c1;
+                    if (NODE_FMT == 10) { c0 = (int)(short)(q.w & 0xFFFFu); c1 = (int)q.w >> 16; }
+                    else {      // one 30-bit index: child 1 follows child 0 (a triangle is three records); bit 31 / 30: child 0 / 1 is a triangle
+                        const uint32_t t = q.w >> 30, base = q.w & kSBaseMask;
+                        c0 = (int)(q.w & ~kSLeaf1);
+                        c1 = (int)((base + (t & 2u) + 1u) | (t << 31));
+                    }
                     const bool h0 = n0 <= f0 * kFarWiden, h1 = n1 <= f1 * kFarWiden;
                     const bool first0 = n0 <= n1;
                     const bool pick0 = h0 && (first0 || !h1);
@@ -594,7 +604,7 @@ k_render_pw(const RenderArgsBox B)
 #pragma unroll
                     for (int leaf = 0; leaf < LEAVES; leaf++)
                     if (node < 0) {
-                        const uint4* tp = (const uint4*)((const char*)sc.srecs + (size_t)(((uint32_t)node & 0x7FFFu) << 4));
+                        const uint4* tp = (const uint4*)((const char*)sc.srecs + (size_t)(((uint32_t)node & (NODE_FMT == 10 ? 0x7FFFu : 0x7FFFFFFFu)) << 4));
                         const uint4 u0 = tp[0], u1 = tp[1], u2 = tp[2];
                         const float4 r0 = make_float4(__uint_as_float(u0.x), __uint_as_float(u0.y), __uint_as_float(u0.z), __uint_as_float(u0.w));
                         const float4 r1 = make_float4(__uint_as_float(u1.x), __uint_as_float(u1.y), __uint_as_float(u1.z), __uint_as_float(u1.w));
@@ -1288,10 +1298,10 @@ static const VariantDesc kVariants[] = {
     ROW(256, 0, "pw K48 L8 fp32 nodes w4, two visits per loop trip (large scenes whose fp16 planes would be too coarse)", 0, 48, 8, 0, 256, 4, false, 0, 2, 1, false, 0, 0),
     ROW(256, 0, "TRIG fp32 nodes w4 with the cosine sampler's sin / cos / acos on v_sin_f32 / v_cos_f32 / sqrt (IEEE mode: everything else IEEE; other bits than its neighbours there)", 0, 48, 12, 0, 256, 4, false, 3, 1, 1, false, 0, 0),
     ROW(256, 8, "pw K44 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes, w4, three visits and two triangle tests per loop trip", 0, 44, 16, 8, 256, 4, false, 0, 3, 2, false, 0, 0),
-    ROW(256, 9, "pw K44 L16 fp16 sign-rotated nodes, five visits per trip + scheduler stats (the default kernel's loop at four waves)", 0, 44, 16, 9, 256, 4, true, 0, 5, 2, false, 0, 0),
-    ROW(256, 9, "pw K40 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes with the rotate amounts in the multipliers' low bits, FIVE waves per SIMD (96 registers), five visits and two triangle tests per loop trip", 0, 40, 16, 9, 256, 5, false, 0, 5, 2, false, 0, 0),
-    ROW(256, 9, "LIGHTS scene-driven area lights + MIS (light mode 1, opt-in: not the reference's estimator), fp16 sign-rotated nodes w4", 0, 44, 16, 9, 256, 4, false, 0, 5, 2, true, 0, 0),
-    ROW(256, 9, "pw K24 L16 fp16 sign-rotated nodes, five waves per SIMD, for large scenes and deep trees: shade rounds at 24 parked lanes (rays are long there), a sliding window of 16 stack entries per lane in LDS, deeper ones moved to global memory four at a time", -16, 24, 16, 9, 256, 5, false, 0, 5, 2, false, -16, 0),
+    ROW(256, 11, "pw K44 L16 fp16 centre / half-extent nodes, five visits per trip + scheduler stats (the default kernel's loop at four waves)", 0, 44, 16, 11, 256, 4, true, 0, 5, 2, false, 0, 0),
+    ROW(256, 11, "pw K40 L16 fp16 nodes (32 B) as centre / half extent per axis: two v_fma_mix_f32 and a full-rate subtract / add per axis and child, no rotates; FIVE waves per SIMD (96 registers), five visits and two triangle tests per loop trip", 0, 40, 16, 11, 256, 5, false, 0, 5, 2, false, 0, 0),
+    ROW(256, 11, "LIGHTS scene-driven area lights + MIS (light mode 1, opt-in: not the reference's estimator), fp16 centre / half-extent nodes w4", 0, 44, 16, 11, 256, 4, false, 0, 5, 2, true, 0, 0),
+    ROW(256, 11, "pw K24 L16 fp16 centre / half-extent nodes, five waves per SIMD, for large scenes and deep trees: shade rounds at 24 parked lanes (rays are long there), a sliding window of 16 stack entries per lane in LDS, deeper ones moved to global memory four at a time", -16, 24, 16, 11, 256, 5, false, 0, 5, 2, false, -16, 0),
 #ifdef ACGPT_EXPERIMENTS
 #include "render_experiments.inc"
 #endif
@@ -1332,7 +1342,7 @@ static size_t variant_lds(const VariantDesc& d, uint32_t stack_entries, uint32_t
 #endif
     if (d.stack_cap > 0 && stack_entries > (uint32_t)d.stack_cap) stack_entries = (uint32_t)d.stack_cap;
     if (d.stack_cap < 0) stack_entries = (uint32_t)(-d.stack_cap) + 1u;      // sliding window: that many entries, whatever the tree, + the window base
-    const uint32_t ent = d.node_fmt == 10 ? 2u : 1u;     // the shared-plane kernel's stack entries are 8 bytes
+    const uint32_t ent = (d.node_fmt == 10 || d.node_fmt == 12) ? 2u : 1u;     // the shared-plane kernel's stack entries are 8 bytes
     size_t lds = (size_t)(d.threads / 64) * (stack_entries * 256u * ent + kBookDwords * 4u) + 256u + (size_t)d.top_n * sizeof(HNode);      // lane stacks, fold bookkeeping, LCG skip-ahead table, staged top of the tree
     if (d.node_fmt == 2) lds += (size_t)n_nodes * sizeof(QNode);
     return lds;

@@ -118,6 +118,19 @@ __global__ void k_selftest(int op, const uint32_t* __restrict__ in, uint32_t n, 
         out[3 * i] = tn <= fminf(tf, r[16]) ? 1u : 0u; fout[3 * i + 1] = tn; fout[3 * i + 2] = tf;
         return;
     }
+    if (op == 40) {
+        // op 19's records through the fp16 centre / half-extent form (NODE_FMT 11): pack_centre_half, setup_ray_hc, slab_hc
+        const float* r = fin + 17 * i;
+        HSpace hs; hs.cx = r[12]; hs.cy = r[13]; hs.cz = r[14]; hs.inv_scale = r[15];
+        const float scale = 1.0f / hs.inv_scale;
+        const uint32_t px = pack_centre_half(r[6], r[9], hs.cx, scale), py = pack_centre_half(r[7], r[10], hs.cy, scale), pz = pack_centre_half(r[8], r[11], hs.cz, scale);
+        f3 mul, add;
+        setup_ray_hc(mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5]), hs, mul, add);
+        float tn, tf;
+        slab_hc(px, py, pz, mul, add, 0.01f, tn, tf);
+        out[3 * i] = tn <= fminf(tf, r[16]) ? 1u : 0u; fout[3 * i + 1] = tn; fout[3 * i + 2] = tf;
+        return;
+    }
     if (op == 39) {
         // the shared-plane kernel's box test end to end (NODE_FMT 10): in = ray o xyz, d xyz, box lo xyz, hi xyz (fp32, as the builder
         // holds it), root planes L xyz, H xyz, inv_scale, tmax.  The box is once child 0 and once child 1 of a node whose other child

@@ -281,15 +281,17 @@ def test_gpu_fp16_slab_is_conservative(ctx):
     for inv_scale in (np.float32(half_ext / np.float32(1023.0)), np.float32(2.0 ** (e - 10))):
         rec = np.concatenate([o, d, lo, hi, np.broadcast_to(centre, (n, 3)), np.full((n, 1), inv_scale, np.float32), tmax[:, None]], axis=1).astype(np.float32)
         assert rec.shape == (n, 17)
-        out = np.zeros((n, 3), np.uint32)
-        run(ctx, 19, np.ascontiguousarray(rec), n, out)
-        accepted = out[:, 0] == 1
-        missed = must & ~accepted
-        assert not missed.any(), "scale %r: box test rejected %d of %d rays that meet the unpadded box, first: %s" % (1.0 / inv_scale, missed.sum(), must.sum(), rec[np.argmax(missed)])
-        # and it is a test, not a constant: rays that miss the box inflated by 2 % of the scene are (almost) never accepted
-        assert accepted[~wide].mean() < 1e-3, accepted[~wide].mean()
-        print("fp16 slab test, planes scaled by %.4f: %.2f %% of the rays that miss the box inflated by 2 %% of the scene are accepted, %.1f %% of all rays"
-              % (1.0 / inv_scale, 100 * accepted[~wide].mean(), 100 * accepted.mean()))
+        # op 19: {lo, hi} planes, rotated by the ray's sign (NODE_FMT 9); op 40: {centre, half extent} (NODE_FMT 11)
+        for op, form in ((19, "lo / hi planes"), (40, "centre / half extent")):
+            out = np.zeros((n, 3), np.uint32)
+            run(ctx, op, np.ascontiguousarray(rec), n, out)
+            accepted = out[:, 0] == 1
+            missed = must & ~accepted
+            assert not missed.any(), "%s, scale %r: box test rejected %d of %d rays that meet the unpadded box, first: %s" % (form, 1.0 / inv_scale, missed.sum(), must.sum(), rec[np.argmax(missed)])
+            # and it is a test, not a constant: rays that miss the box inflated by 2 % of the scene are (almost) never accepted
+            assert accepted[~wide].mean() < 1e-3, accepted[~wide].mean()
+            print("fp16 slab test, %s, scaled by %.4f: %.2f %% of the rays that miss the box inflated by 2 %% of the scene are accepted, %.1f %% of all rays"
+                  % (form, 1.0 / inv_scale, 100 * accepted[~wide].mean(), 100 * accepted.mean()))
 
 
 def test_gpu_shared_plane_slab_is_conservative(ctx):

@@ -65,8 +65,21 @@ def main():
                 lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "acgpathtracing_amd", os.environ.get("ACGPT_HIP_LIB", "libacgpt_hip.so"))
                 vm = valu_mix.kernel_mix(lib, inst)
                 out["valu_mix"] = vm
-                der["valu_issue_busy_mix"] = g("SQ_INSTS_VALU") * vm["cycles_per_valu_spec"] / (cyc * 1024)
-                der["valu_issue_busy_ubench"] = g("SQ_INSTS_VALU") * vm["cycles_per_valu_priced"] / (cyc * 1024)
+                spec, priced = vm["cycles_per_valu_spec"], vm["cycles_per_valu_priced"]
+                if g("SQ_ACTIVE_INST_VALU2") is not None and g("SQ_INSTS_VALU_TRANS_F32") is not None:
+                    # the DYNAMIC class shares, from counters calibrated with the microbenchmark (profiles/r04_valu_class_counters.txt):
+                    # SQ_ACTIVE_INST_VALU2 advances 0.42 per full-rate instruction and not at all for the others; TRANS_F32 counts the quarter-rate ones
+                    n = g("SQ_INSTS_VALU")
+                    full = min(1.0, g("SQ_ACTIVE_INST_VALU2") / 0.42 / n)
+                    quarter = g("SQ_INSTS_VALU_TRANS_F32") / n
+                    half = max(0.0, 1.0 - full - quarter)
+                    cs, cu = vm["class_cycles_spec"], vm["class_cycles"]
+                    spec = full * cs["full"] + half * cs["half"] + quarter * cs["quarter"]
+                    priced = full * cu["full"] + half * cu["half"] + quarter * cu["quarter"]
+                    out["valu_class_shares"] = {"full_rate": full, "half_rate": half, "quarter_rate": quarter, "source": "SQ_ACTIVE_INST_VALU2 / 0.42, SQ_INSTS_VALU_TRANS_F32 (dynamic; calibration: profiles/r04_valu_class_counters.txt)",
+                                                "static_mix_would_give": {"cycles_per_valu_spec": vm["cycles_per_valu_spec"]}}
+                der["valu_issue_busy_mix"] = g("SQ_INSTS_VALU") * spec / (cyc * 1024)
+                der["valu_issue_busy_ubench"] = g("SQ_INSTS_VALU") * priced / (cyc * 1024)
             except Exception as e:
                 out["valu_mix"] = {"error": str(e)}
         if g("TA_TA_BUSY_sum"):

@@ -333,6 +333,42 @@ BODY(k_pair_rcp_fmamix, A_PAIR_RCP_FMAMIX)
 #define A_PAIR_LSHLOR_FMAMIX(n) A_LSHLOR(n) PAIR_CALL(A_FMAMIX, PAIR_ALT_##n)
 BODY(k_pair_lshlor_fmamix, A_PAIR_LSHLOR_FMAMIX)
 
+// round 4: does a full-rate instruction overlap a half-rate NEIGHBOUR (same wave, adjacent), or any half-rate instruction in flight on the
+// SIMD (another wave's)?  The same 4 + 4 instructions per group of eight, once alternating (the PAIR rows) and once in blocks of four.
+#define A_BLK_FMA_MAX_0(n) A_FMA(n)
+#define A_BLK_SEL(n) A_BLK_SEL_##n
+#define A_BLK4(n) PAIR_CALL(A_BLK4_, n)
+#define A_BLK4_0 A_FMA(0)
+#define A_BLK4_1 A_FMA(1)
+#define A_BLK4_2 A_FMA(2)
+#define A_BLK4_3 A_FMA(3)
+#define A_BLK4_4 A_MAX(4)
+#define A_BLK4_5 A_MAX(5)
+#define A_BLK4_6 A_MAX(6)
+#define A_BLK4_7 A_MAX(7)
+#define A_BLK4X(n) A_BLK4_##n
+BODY(k_blk4_fma_max, A_BLK4X)
+#define A_BLKM_0 A_FMAMIX(0)
+#define A_BLKM_1 A_FMAMIX(1)
+#define A_BLKM_2 A_FMAMIX(2)
+#define A_BLKM_3 A_FMAMIX(3)
+#define A_BLKM_4 A_SUB(4)
+#define A_BLKM_5 A_SUB(5)
+#define A_BLKM_6 A_SUB(6)
+#define A_BLKM_7 A_SUB(7)
+#define A_BLKMX(n) A_BLKM_##n
+BODY(k_blk4_mix_sub, A_BLKMX)
+#define A_ALT_0 A_FMA(0)
+#define A_ALT_1 A_MAX(1)
+#define A_ALT_2 A_FMA(2)
+#define A_ALT_3 A_MAX(3)
+#define A_ALT_4 A_FMA(4)
+#define A_ALT_5 A_MAX(5)
+#define A_ALT_6 A_FMA(6)
+#define A_ALT_7 A_MAX(7)
+#define A_ALTX(n) A_ALT_##n
+BODY(k_alt_fma_max, A_ALTX)
+
 typedef void (*Kern)(int, float*);
 struct Desc { const char* name; Kern k; };
 
@@ -353,6 +389,7 @@ int main()
                        {"v_bfi_b32", k_bfi}, {"v_min3_f32", k_min3}, {"v_sub_f32", k_sub}, {"v_xor_b32", k_xor}, {"v_mad_u32_u24", k_mad24}, {"v_rcp_f32", k_rcp}, {"v_mov_b32", k_mov}, {"v_lshl_or_b32", k_lshlor}, {"v_and_or_b32", k_andor}, {"s_and_b64 (scalar)", k_salu},
                        {"v_pk_max_i16", k_pkmaxi}, {"v_pk_max_u16", k_pkmaxu}, {"v_cvt_pkrtz_f16_f32", k_cvtpk}, {"v_or_b32", k_or}, {"v_fma_mix_f32 |src0| (abs modifier)", k_mixabs},
                        {"PAIR v_fma_mix_f32 + v_fma_f32", k_mixfma}, {"PAIR v_max_f32 + v_fma_f32", k_maxfma},
+                       {"GROUP of 8 (x0.125): 4 v_fma_f32 then 4 v_max_f32", k_blk4_fma_max}, {"GROUP of 8 (x0.125): fma max fma max ...", k_alt_fma_max}, {"GROUP of 8 (x0.125): 4 v_fma_mix_f32 then 4 v_sub_f32", k_blk4_mix_sub},
                        {"PAIR v_alignbit_b32 + v_fma_f32", k_pair_alignbit_fma},
                        {"PAIR v_max_f32 + v_fma_f32", k_pair_max_fma},
                        {"PAIR v_max3_f32 + v_fma_f32", k_pair_max3_fma},
