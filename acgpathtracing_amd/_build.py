@@ -16,7 +16,7 @@ HOST = os.path.join(PKG, "host")
 
 HIP_SOURCES = ["capi.hip", "lbvh_build.hip", "wide_bvh.hip", "render_megakernel.hip", "selftest.hip"]
 EXPERIMENT_SOURCES = ["render_wavefront.hip"]      # kernels that were measured and lost: libacgpt_hip_exp.so only
-HIP_HEADERS = ["pt_device.h", "pt_shading.h", "lbvh_build.h", "render_megakernel.h", "render_common.h", "render_experiments.inc", "selftest.h"]
+HIP_HEADERS = ["pt_device.h", "pt_shading.h", "lbvh_build.h", "render_megakernel.h", "render_common.h", "render_experiments.inc", "lbvh_experiments.inc", "selftest.h"]
 HOST_SOURCES = ["host_capi.cpp", "TinyObjWrapper.cpp", "Camera.cpp", "Trackball.cpp", "ImageIO.cpp"]
 
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-fvisibility=hidden", "-std=c++17"]

@@ -160,6 +160,8 @@ def hip():
     L.pt_debug_queue_progress.argtypes = [vp, vp]; L.pt_debug_queue_progress.restype = C.c_int
     L.pt_read_morton.argtypes = [vp, vp, vp]; L.pt_read_morton.restype = C.c_int
     L.pt_debug_window_moves.argtypes = [vp, vp]; L.pt_debug_window_moves.restype = C.c_int
+    if hasattr(L, "pt_debug_node_order"):      # experiments library only
+        L.pt_debug_node_order.argtypes = [vp, C.c_int]; L.pt_debug_node_order.restype = C.c_int
     if hasattr(L, "pt_debug_wf"):      # experiments library only
         L.pt_debug_wf.argtypes = [vp, vp]; L.pt_debug_wf.restype = C.c_int
     L.pt_debug_queue_order.argtypes = [vp, C.c_int]; L.pt_debug_queue_order.restype = C.c_int

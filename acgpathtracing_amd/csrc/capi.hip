@@ -366,8 +366,10 @@ static int ensure_node_format(pt_ctx* c, int fmt)
         case 6: ok = ptd::ensure_cnodes(c->bvh, c->stream, err); break;
         case 3: return ensure_wide(c);
         case 11: ok = ptd::ensure_hcnodes(c->bvh, c->stream, err); break;
+#ifdef ACGPT_EXPERIMENTS
         case 10: ok = ptd::ensure_srecs(c->bvh, false, c->stream, err); break;       // 15-bit child references: scenes up to ~8 000 triangles
         case 12: ok = ptd::ensure_srecs(c->bvh, true, c->stream, err); break;
+#endif
         default: return fail(c, "unknown node format");
     }
     return ok ? 0 : fail(c, err);
@@ -612,7 +614,7 @@ PT_API int pt_set_stream(pt_ctx* c, void* s)
 static ptd::DeviceScene device_scene(pt_ctx* c)
 {
     ptd::DeviceScene sc;
-    sc.nodes = c->bvh.nodes; sc.qnodes = c->bvh.qnodes; sc.cnodes = c->bvh.cnodes; sc.hnodes = c->bvh.hnodes; sc.top = c->bvh.top_nodes; sc.n_top = c->bvh.n_top; sc.hspace = c->bvh.hspace; sc.grid = c->bvh.grid; sc.tris = c->bvh.tris; sc.shade = c->bvh.shade; sc.wrecs = c->bvh.wrecs; sc.hcnodes = c->bvh.hcnodes; sc.srecs = c->bvh.srecs; sc.sspace = c->bvh.sspace; sc.mats = c->d_mats;
+    sc.nodes = c->bvh.nodes; sc.qnodes = c->bvh.qnodes; sc.cnodes = c->bvh.cnodes; sc.hnodes = c->bvh.hnodes; sc.top = c->bvh.top_nodes; sc.n_top = c->bvh.n_top; sc.hspace = c->bvh.hspace; sc.grid = c->bvh.grid; sc.tris = c->bvh.tris; sc.shade = c->bvh.shade; sc.wrecs = c->bvh.wrecs; sc.hcnodes = c->bvh.hcnodes_alt ? c->bvh.hcnodes_alt : c->bvh.hcnodes; sc.srecs = c->bvh.srecs; sc.sspace = c->bvh.sspace; sc.mats = c->d_mats;
     sc.n_tris = c->bvh.n_tris; sc.n_mats = c->n_mats;
     sc.lights = c->d_lights; sc.n_lights = c->n_lights; sc.light_area = c->light_area;
     return sc;
@@ -1262,6 +1264,17 @@ PT_API int pt_debug_window_moves(pt_ctx* c, uint64_t* out)
 }
 
 #ifdef ACGPT_EXPERIMENTS
+// experiments build only: renumber the resident fp16 nodes (0: the build's order, 1: sibling pairs share a 64-byte line, 2: depth first)
+PT_API int pt_debug_node_order(pt_ctx* c, int mode)
+{
+    if (!c || mode < 0 || mode > 2) return fail(c, "pt_debug_node_order: mode 0, 1 or 2");
+    CK(c, hipSetDevice(c->device));
+    CK(c, hipStreamSynchronize(c->stream));
+    std::string err;
+    if (!ptd::reorder_hcnodes(c->bvh, mode, c->stream, err)) return fail(c, "pt_debug_node_order: " + err);
+    return 0;
+}
+
 // experiments build only: per-role times of the last launch of a wavefront kernel (render_wavefront.hip), 17 values (tools/wf_check.py)
 PT_API int pt_debug_wf(pt_ctx* c, uint64_t* out)
 {

@@ -24,6 +24,8 @@ struct LbvhResult {
     QGrid      grid = {};              // world -> grid transform of qnodes
     TriRecord* tris = nullptr;         // device, n_tris, Morton order
     float4*    shade = nullptr;        // device, n_tris, same order: geometric normal + material id (pt_device.h DeviceScene::shade)
+    HNode*     hcnodes_alt = nullptr;  // experiments build: a renumbered copy of hcnodes (reorder_hcnodes), what the kernels walk while it exists
+    size_t     hcnodes_alt_bytes = 0;
     HNode*     hcnodes = nullptr;      // device, n_nodes: fp16 centre | half-extent boxes, child references as byte offsets (NODE_FMT 11; ensure_hcnodes)
     uint4*     srecs = nullptr;        // device, n_srecs x 16 B: shared-plane nodes + triangles in one array (NODE_FMT 10; ensure_srecs)
     uint32_t   n_srecs = 0;
@@ -55,7 +57,11 @@ bool ensure_hnodes(LbvhResult& r, hipStream_t stream, std::string& err);
 bool ensure_qnodes(LbvhResult& r, hipStream_t stream, std::string& err);
 bool ensure_cnodes(LbvhResult& r, hipStream_t stream, std::string& err);
 bool ensure_hcnodes(LbvhResult& r, hipStream_t stream, std::string& err);    // fp16 centre / half-extent nodes (NODE_FMT 11), from the fp32 nodes
-bool ensure_srecs(LbvhResult& r, bool wide_refs, hipStream_t stream, std::string& err);      // shared-plane records (NODE_FMT 10), from the fp32 nodes
+#ifdef ACGPT_EXPERIMENTS
+bool ensure_srecs(LbvhResult& r, bool wide_refs, hipStream_t stream, std::string& err);      // shared-plane records (NODE_FMT 10 / 12), from the fp32 nodes
+// experiment: renumber the centre / half-extent nodes (0: the build's order; 1: sibling pairs in one 64-byte line; 2: depth first)
+bool reorder_hcnodes(LbvhResult& r, int mode, hipStream_t stream, std::string& err);
+#endif      // shared-plane records (NODE_FMT 10), from the fp32 nodes
 // (Morton code, original triangle index) per leaf slot in sorted order, recomputed from the records (the build keeps no copy of its sort keys)
 bool read_morton(const LbvhResult& r, hipStream_t stream, uint32_t* h_codes, uint32_t* h_prims, std::string& err);
 // bytes of device memory the scene's arrays hold right now

@@ -701,6 +701,7 @@ void free_lbvh(LbvhResult& r)
     if (r.wrecs) (void)hipFree(r.wrecs);
     if (r.srecs) (void)hipFree(r.srecs);
     if (r.hcnodes) (void)hipFree(r.hcnodes);
+    if (r.hcnodes_alt) (void)hipFree(r.hcnodes_alt);
     r = LbvhResult();
 }
 
@@ -889,76 +890,6 @@ bool build_top_nodes(LbvhResult& r, hipStream_t stream, std::string& err)
     return true;
 }
 
-// --- 11. shared-plane records (NODE_FMT 10; pt_device.h SSpace) ---------------------------------------------------------------
-// From the fp32 nodes: one 16-byte record per inner node and the 48-byte triangle records, in ONE array in which the two children of
-// every node are contiguous (child 0, then child 1; a triangle takes three records).  Record 0 is the root; the children pairs follow in
-// node-index order (PLOC numbers its nodes top-down, so this is close to breadth first).  Three passes over the nodes and one over the
-// triangles; positions from an exclusive scan of the pair sizes.
-__device__ __forceinline__ uint32_t s_child_size(int c, bool single) { return c >= 0 ? 1u : (single ? 0u : 3u); }
-__global__ void k_s_sizes(const BvhNode* __restrict__ nodes, uint32_t n_nodes, bool single_tri, uint32_t* __restrict__ sizes)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_nodes) return;
-    const int4 ch = nodes[i].d;
-    // a single-triangle scene has one node whose second child is an empty box over the same triangle: it takes no records
-    sizes[i] = s_child_size(ch.x, false) + s_child_size(ch.y, single_tri);
-}
-__global__ void k_s_place(const BvhNode* __restrict__ nodes, uint32_t n_nodes, const uint32_t* __restrict__ base /* exclusive scan of sizes */,
-                          uint32_t* __restrict__ pos_node, uint32_t* __restrict__ pos_tri)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_nodes) return;
-    const int4 ch = nodes[i].d;
-    const uint32_t p0 = 1u + base[i], p1 = p0 + s_child_size(ch.x, false);
-    if (ch.x >= 0) pos_node[ch.x] = p0; else pos_tri[~ch.x] = p0;
-    if (ch.y >= 0) pos_node[ch.y] = p1; else if (~ch.y != ~ch.x || ch.x >= 0) pos_tri[~ch.y] = p1;
-    if (i == 0u) pos_node[0] = 0u;
-}
-__global__ void k_s_nodes(const BvhNode* __restrict__ nodes, uint32_t n_nodes, const uint32_t* __restrict__ base, const uint32_t* __restrict__ pos_node,
-                          const uint32_t* __restrict__ pos_tri, SSpace sp, bool wide_refs, uint4* __restrict__ recs)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_nodes) return;
-    const BvhNode nd = nodes[i];
-    const float scale = 1.0f / sp.inv_scale;
-    // child 0: lo (a.x a.y a.z) hi (a.w b.x b.y); child 1: lo (b.z b.w c.x) hi (c.y c.z c.w)
-    const float l0[3] = {nd.a.x, nd.a.y, nd.a.z}, h0[3] = {nd.a.w, nd.b.x, nd.b.y}, l1[3] = {nd.b.z, nd.b.w, nd.c.x}, h1[3] = {nd.c.y, nd.c.z, nd.c.w};
-    const float L[3] = {sp.lx, sp.ly, sp.lz}, H[3] = {sp.hx, sp.hy, sp.hz};
-    const bool empty1 = !(l1[0] <= h1[0]);
-    uint32_t w[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        if (empty1) {
-            // child 0 keeps its own planes; child 1's "box" is empty for every ray: both of its planes as far inside as the format reaches
-            w[k] = pack_magnitude(l0[k] - L[k], scale, false) | (pack_magnitude(H[k] - h0[k], scale, false) << 16);
-            if (k == 0) w[k] = (pack_magnitude(3.0e38f, scale, true)) | (pack_magnitude(3.0e38f, scale, true) << 16);
-        } else {
-            w[k] = s_new_plane(l0[k] - L[k], l1[k] - L[k], scale) | (s_new_plane(H[k] - h0[k], H[k] - h1[k], scale) << 16);
-        }
-    }
-    // children: two 16-bit references, child 0 in the low half: record index in 15 bits, bit 15 = the child is a triangle
-    // (ensure_srecs refuses scenes with more than 32 767 records; larger scenes would take a 32-bit form of this word)
-    const int c0 = nd.d.x, c1 = nd.d.y;
-    const uint32_t i0 = 1u + base[i], i1 = i0 + s_child_size(c0, false);
-    // ... or, for larger scenes (NODE_FMT 12), one 30-bit index: child 0's; child 1 follows it (one record further, three if child 0 is a
-    // triangle); bit 31 / 30: child 0 / child 1 is a triangle (pt_device.h kSLeaf0 / kSLeaf1)
-    const uint32_t ref = wide_refs ? (i0 | (c0 < 0 ? kSLeaf0 : 0u) | (c1 < 0 ? kSLeaf1 : 0u))
-                                   : ((i0 & 0x7FFFu) | (c0 < 0 ? 0x8000u : 0u) | (((i1 & 0x7FFFu) | (c1 < 0 ? 0x8000u : 0u)) << 16));
-    (void)pos_tri;
-    recs[pos_node[i]] = make_uint4(w[0], w[1], w[2], ref);
-}
-__global__ void k_s_tris(const TriRecord* __restrict__ tris, uint32_t n_tris, const uint32_t* __restrict__ pos_tri, uint4* __restrict__ recs)
-{
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_tris) return;
-    const uint4* src = (const uint4*)(tris + s);
-    uint4* dst = recs + pos_tri[s];
-    dst[0] = src[0]; dst[1] = src[1];
-    uint4 r2 = src[2];
-    r2.w = s;                     // the leaf slot (index into DeviceScene::shade): what a hit on this record reports
-    dst[2] = r2;
-}
-
 // ---- node arrays on demand ------------------------------------------------------------------------------------------------
 static bool sync_ok(hipStream_t stream, const char* what, std::string& err)
 {
@@ -1051,76 +982,9 @@ bool ensure_hcnodes(LbvhResult& r, hipStream_t stream, std::string& err)
     return sync_ok(stream, "fp16 centre / half-extent nodes", err);
 }
 
-// shared-plane records, on first use by a kernel variant that walks them (NODE_FMT 10)
-bool ensure_srecs(LbvhResult& r, bool wide_refs, hipStream_t stream, std::string& err)
-{
-    if (r.srecs && r.srecs_wide != wide_refs) { (void)hipFree(r.srecs); r.srecs = nullptr; r.n_srecs = 0; }
-    if (r.srecs || r.n_tris == 0) return true;
-    if (!ensure_nodes(r, stream, err)) return false;
-    Scratch sc;
-    const uint32_t n = r.n_tris, n_nodes = r.n_nodes;
-    uint32_t *d_sizes, *d_pos_node, *d_pos_tri;
-    HIPCK(sc.alloc(&d_sizes, ((size_t)n_nodes + 1) * 4));
-    HIPCK(sc.alloc(&d_pos_node, (size_t)n_nodes * 4));
-    HIPCK(sc.alloc(&d_pos_tri, (size_t)n * 4));
-    const uint32_t n_recs = n_nodes + 3u * n;
-    if ((uint64_t)n_nodes + 3ull * n >= (1ull << 28)) { err = "shared-plane records: the kernels address them with 32-bit byte offsets (2^28 records)"; return false; }
-    // the root's planes: the scene box, a little outside (magnitudes are measured inward from them and must not be negative); one unit
-    // of magnitude = 1 / 2046 of the longest extent, so that every magnitude is an fp16 value below 2048 (exact integers; finer near the root planes)
-    SSpace sp;
-    float ext = 0.0f;
-    float* L = &sp.lx; float* H = &sp.hx;
-    for (int k = 0; k < 3; k++) {
-        const float e = r.scene_hi[k] - r.scene_lo[k], pad = fmaxf(e, 1e-30f) * 1e-4f + r.pad_abs;
-        L[k] = r.scene_lo[k] - pad; H[k] = r.scene_hi[k] + pad;
-        ext = fmaxf(ext, H[k] - L[k]);
-    }
-    sp.inv_scale = (ext > 0.0f && ext < INFINITY ? ext : 1.0f) / 2046.0f;
-    HIPCK(hipMalloc((void**)&r.srecs, (size_t)n_recs * sizeof(uint4)));
-    const uint32_t nb = (n_nodes + 255) / 256;
-    k_s_sizes<<<nb, 256, 0, stream>>>(r.nodes, n_nodes, n == 1, d_sizes);
-    k_scan<<<1, 1024, 0, stream>>>(d_sizes, n_nodes);
-    k_s_place<<<nb, 256, 0, stream>>>(r.nodes, n_nodes, d_sizes, d_pos_node, d_pos_tri);
-    k_s_nodes<<<nb, 256, 0, stream>>>(r.nodes, n_nodes, d_sizes, d_pos_node, d_pos_tri, sp, wide_refs, r.srecs);
-    k_s_tris<<<(n + 255) / 256, 256, 0, stream>>>(r.tris, n, d_pos_tri, r.srecs);
-    r.n_srecs = n_recs;
-    r.sspace = sp;
-    r.srecs_wide = wide_refs;
-    if (!sync_ok(stream, "shared-plane records", err)) return false;
-    if (!wide_refs && n_recs > 32767u) { err = "shared-plane records with 15-bit child references: more than 32 767 records"; return false; }
-    if (n_recs <= (8u << 20)) {
-        // a walk over what was written, on the host, before any kernel follows these references: every record reached exactly once,
-        // every triangle exactly once, nothing outside the array (the kernels trust the references blindly)
-        std::vector<uint4> h(n_recs);
-        HIPCK(hipMemcpy(h.data(), r.srecs, (size_t)n_recs * sizeof(uint4), hipMemcpyDeviceToHost));
-        std::vector<uint8_t> seen(n_recs, 0);
-        std::vector<uint32_t> todo(1, 0u);
-        uint32_t inner = 0, leaves = 0;
-        bool ok = true;
-        while (!todo.empty() && ok) {
-            const uint32_t at = todo.back(); todo.pop_back();
-            if (at >= n_recs || seen[at]) { ok = false; break; }
-            seen[at] = 1; inner++;
-            const uint32_t w = h[at].w;
-            for (int k = 0; k < 2 && ok; k++) {
-                uint32_t idx; bool is_leaf;
-                if (wide_refs) { const bool l0 = (w & kSLeaf0) != 0; idx = (w & kSBaseMask) + (k ? (l0 ? 3u : 1u) : 0u); is_leaf = (w & (k ? kSLeaf1 : kSLeaf0)) != 0; }
-                else { const uint32_t c = (w >> (16 * k)) & 0xFFFFu; idx = c & 0x7FFFu; is_leaf = (c & 0x8000u) != 0; }
-                if (n == 1 && k == 1) continue;                        // the empty second child of a single-triangle scene
-                if (is_leaf) {
-                    if (idx + 2u >= n_recs || seen[idx] || h[idx + 2].w >= n) ok = false;
-                    else { seen[idx] = seen[idx + 1] = seen[idx + 2] = 1; leaves++; }
-                } else todo.push_back(idx);
-            }
-        }
-        if (!ok || inner != n_nodes || leaves != n) {
-            (void)hipFree(r.srecs); r.srecs = nullptr; r.n_srecs = 0;
-            err = "shared-plane records: inconsistent child references (" + std::to_string(inner) + " nodes, " + std::to_string(leaves) + " triangles reached)";
-            return false;
-        }
-    }
-    return true;
-}
+#ifdef ACGPT_EXPERIMENTS
+#include "lbvh_experiments.inc"      // builders of formats that were measured and not adopted; not part of the product's kernel-source hash
+#endif
 
 // (Morton code, original triangle index) of every leaf slot, as the sort saw them: recomputed from the records, HOST outputs
 bool read_morton(const LbvhResult& r, hipStream_t stream, uint32_t* h_codes, uint32_t* h_prims, std::string& err)
@@ -1153,6 +1017,7 @@ size_t scene_device_bytes(const LbvhResult& r)
     if (r.wrecs) b += (size_t)r.n_wrecs * 48u;
     if (r.srecs) b += (size_t)r.n_srecs * sizeof(uint4);
     if (r.hcnodes) b += (size_t)r.n_nodes * sizeof(HNode);
+    b += r.hcnodes_alt_bytes;
     return b;
 }
 

@@ -334,6 +334,8 @@ def main():
         assert L.pt_set_tuning(state.context, a.blocks_per_cu, a.variant if a.variant >= 0 else -1) == 0
     math_mode = _native.MATH_FAST if a.math == "fast" else _native.MATH_IEEE
     assert L.pt_set_math_mode(state.context, math_mode) == 0
+    if os.environ.get("ACGPT_NODE_ORDER"):          # experiments library only (tools/): renumbered fp16 nodes, same bits
+        assert L.pt_debug_node_order(state.context, int(os.environ["ACGPT_NODE_ORDER"])) == 0, L.pt_last_error(state.context)
     info = pt.getBvhInfo(state)
 
     fuse = max(1, min(a.fuse, 64, a.steps))
@@ -440,7 +442,8 @@ def main():
                        "primary_miss_fraction": miss, "culled_rays": int(tot_culled), "rays_entering_scene": int(all_rays - tot_culled),
                        "Mray_per_s_entering_scene": (all_rays - tot_culled) / elapsed / 1e6,
                        "sample_runs_per_pixel": int(last_stats.sample_chunks),
-                       "bvh": {"nodes": info.n_nodes, "max_depth": info.max_depth, "stack_entries": info.stack_entries, "build_ms": info.build_ms}},
+                       "bvh": {"nodes": info.n_nodes, "max_depth": info.max_depth, "stack_entries": info.stack_entries, "build_ms": info.build_ms},
+                       "scene_device_bytes": int(pt.getBvhInfo(state).device_bytes)},      # what the scene holds on the device after the run (one node array + triangle + shading records)
             "roofline": roof,
         }
         if other_math:

@@ -80,6 +80,9 @@ int pt_debug_row_spans(const pt_params* params, const float* box_lo, const float
  * memory (wave-level events; 0 for the kernels that keep the whole stack in LDS). */
 int pt_debug_window_moves(pt_ctx* ctx, uint64_t* out);
 #ifdef ACGPT_EXPERIMENTS
+/* Experiments library only: walk a renumbered copy of the fp16 nodes (0: the build's order; 1: the two children of a node in one 64-byte
+ * line; 2: depth first).  Same bits; an A/B of the memory system on large scenes (profiles/r04_ab_node_order.txt). */
+int pt_debug_node_order(pt_ctx* ctx, int mode);
 /* Experiments library only (libacgpt_hip_exp.so, -DACGPT_EXPERIMENTS; never the product): 17 values after a launch of a wavefront
  * kernel variant (render_wavefront.hip), summed over the waves of the grid, times in 10 ns ticks: trace waves {total, idle},
  * shade waves {total, idle, deal time / rounds / records, hit-shading time / rounds / records, accounting time / rounds /
