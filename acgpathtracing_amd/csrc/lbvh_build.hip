@@ -369,6 +369,7 @@ __global__ void k_single_node(const float4* __restrict__ tri_lo, const float4* _
 // Karras tree, profiles/r01_bvh_quality.txt).  Deterministic: ties go to the lower index and node
 // numbers come from prefix sums, not atomics.  Node 0 is the root (numbers are handed out downwards).
 constexpr int kPlocRadius = 8;
+constexpr uint32_t kDepthFirstTris = 50000;      // scenes above this many triangles get their nodes in depth-first order (6a): where the tree outgrows the caches
 
 struct Cluster {
     float4 lo;   // .w = node reference as int bits (>= 0 inner node, < 0 leaf ~slot)
@@ -493,6 +494,71 @@ __global__ void k_ploc_advance(PlocState* __restrict__ st)
     st->rounds += 1u;
 }
 
+
+// --- 6a. depth-first numbering of the nodes (large scenes) ---------------------------------------------------------------------
+// PLOC hands out node numbers by merge round (root last = 0), Karras by position in the sorted order: neither keeps a root-to-leaf
+// descent inside few cache lines.  In depth-first (pre-)order a node is followed by its first child's whole subtree, so the deeper
+// a ray is, the closer together the nodes it visits next: on the scenes that do not fit the L2 the render kernel's L2 hit rate goes
+// from 0.61 to 0.68 (10.5 M triangles; 0.73 -> 0.76 at 1.31 M) and the bytes between L2 and fabric drop by a fifth, for 2.8 % / 0.8 % of the
+// time (profiles/r04_ab_node_order.txt; sibling pairs in one 64-byte line: nothing).  Done on the fp32 nodes, before any other array
+// is derived from them, so every format shares the numbering.  pre(child0) = pre(parent) + 1, pre(child1) = pre(parent) + 1 +
+// |inner nodes under child0|: subtree sizes bottom-up (the second arrival at a node proceeds, as in k_refit), then every node
+// walks up to the root adding what lies before it (tree depth steps).
+__global__ void k_dfs_parents(const BvhNode* __restrict__ nodes, uint32_t n_nodes, int* __restrict__ parent)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const int4 ch = nodes[i].d;
+    if (ch.x >= 0) parent[ch.x] = (int)i;
+    if (ch.y >= 0) parent[ch.y] = (int)i;
+    if (i == 0u) parent[0] = -1;
+}
+__global__ void k_dfs_sizes(const BvhNode* __restrict__ nodes, uint32_t n_nodes, const int* __restrict__ parent, uint32_t* __restrict__ visit, uint32_t* __restrict__ size)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    int4 ch = nodes[i].d;
+    if (ch.x >= 0 || ch.y >= 0) return;                      // start at the nodes whose children are both triangles
+    int cur = (int)i;
+    uint32_t s = 1u;
+    for (;;) {
+        size[cur] = s;
+        const int p = parent[cur];
+        if (p < 0) return;
+        ch = nodes[p].d;
+        const bool both_inner = ch.x >= 0 && ch.y >= 0;
+        if (both_inner) {
+            // release this subtree's size, acquire the sibling's: the second arrival proceeds
+            const uint32_t prev = __hip_atomic_fetch_add(&visit[p], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (prev == 0u) return;
+            s = 1u + __hip_atomic_load(&size[ch.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + __hip_atomic_load(&size[ch.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            s = 1u + s;                                       // the other child is a triangle
+        }
+        cur = p;
+    }
+}
+__global__ void k_dfs_index(const BvhNode* __restrict__ nodes, uint32_t n_nodes, const int* __restrict__ parent, const uint32_t* __restrict__ size, uint32_t* __restrict__ newidx)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    uint32_t before = 0u;
+    int cur = (int)i;
+    for (int p = parent[cur]; p >= 0; cur = p, p = parent[cur]) {
+        const int4 ch = nodes[p].d;
+        before += 1u + ((ch.y == cur && ch.x >= 0) ? size[ch.x] : 0u);      // the parent itself, and the first child's subtree if this is the second
+    }
+    newidx[i] = before;
+}
+__global__ void k_dfs_permute(const BvhNode* __restrict__ nodes, uint32_t n_nodes, const uint32_t* __restrict__ newidx, BvhNode* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    BvhNode nd = nodes[i];
+    if (nd.d.x >= 0) nd.d.x = (int)newidx[nd.d.x];
+    if (nd.d.y >= 0) nd.d.y = (int)newidx[nd.d.y];
+    out[newidx[i]] = nd;
+}
 
 // --- 6b. 16-bit grid copy of the nodes (experiment formats 1 / 2 / 4; built on first use from the fp32 nodes) -------------
 __global__ void k_quant_nodes(const BvhNode* __restrict__ nodes, uint32_t n, const QGrid g, QNode* __restrict__ qn)
@@ -812,6 +878,24 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
         k_single_node<<<1, 1, 0, stream>>>(d_tlo, d_thi, out.nodes, d_nhi);
     }
     HIPCK(hipGetLastError());
+    if (n > kDepthFirstTris) {         // large scenes: the nodes in depth-first order (6a)
+        int* d_par; uint32_t *d_size, *d_new; BvhNode* d_sorted = nullptr;
+        HIPCK(sc.alloc(&d_par, (size_t)n_nodes * 4));
+        HIPCK(sc.alloc(&d_size, (size_t)n_nodes * 4));
+        HIPCK(sc.alloc(&d_new, (size_t)n_nodes * 4));
+        HIPCK(hipMemsetAsync(d_visit, 0, (size_t)n_nodes * 4, stream));
+        const uint32_t nbk = (n_nodes + 255) / 256;
+        k_dfs_parents<<<nbk, 256, 0, stream>>>(out.nodes, n_nodes, d_par);
+        k_dfs_sizes<<<nbk, 256, 0, stream>>>(out.nodes, n_nodes, d_par, d_visit, d_size);
+        k_dfs_index<<<nbk, 256, 0, stream>>>(out.nodes, n_nodes, d_par, d_size, d_new);
+        HIPCK(hipMalloc((void**)&d_sorted, (size_t)n_nodes * sizeof(BvhNode)));
+        k_dfs_permute<<<nbk, 256, 0, stream>>>(out.nodes, n_nodes, d_new, d_sorted);
+        hipError_t e_ = hipGetLastError();
+        if (e_ == hipSuccess) e_ = hipStreamSynchronize(stream);
+        if (e_ != hipSuccess) { (void)hipFree(d_sorted); err = std::string("depth-first numbering: ") + hipGetErrorString(e_); return false; }
+        (void)hipFree(out.nodes);
+        out.nodes = d_sorted;
+    }
     HIPCK(hipEventRecord(sc.ev1, stream));
     HIPCK(hipMemcpyAsync(h_bounds, d_bounds, 24, hipMemcpyDeviceToHost, stream));
     HIPCK(hipMemcpyAsync(&root_hi, d_nhi, 16, hipMemcpyDeviceToHost, stream));
