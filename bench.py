@@ -416,7 +416,7 @@ def main():
                               vname.decode() if vname else "?", vkern.decode() if vkern else "", L.pt_kernel_source_hash().decode())
         miss = primary_miss_fraction(p, info)
         out = {
-            "metric": "Mray/s at %s, %d spp, %d bounces (radiance + shadow rays per second; camera rays that miss the scene box are radiance segments too and are counted, see config.culled_rays)"
+            "metric": "Mray/s at %s, %d spp, %d bounces (radiance + shadow rays per second; camera rays that miss the scene box are radiance segments too and are counted — the rays the kernel traverses are Mray_per_s_entering_scene beside `value`)"
                       % ("1080p" if (a.width, a.height) == (WIDTH, HEIGHT) else "%dx%d" % (a.width, a.height), a.spp * a.steps, a.max_depth),
             "value": all_rays / elapsed / 1e6,
             "unit": "Mray/s",
