@@ -57,7 +57,7 @@ struct pt_ctx {
     uint32_t stack_entries = 8;
     int blocks_per_cu = 0;        // from the occupancy query for the current stack size
     int tune_blocks_per_cu = 0;   // user override
-    int build_mode = 1;           // 0 Karras LBVH, 1 PLOC over the Morton order
+    int build_mode = 2;           // 0 Karras LBVH, 1 PLOC over the Morton order, 2 PLOC + insertion-based optimisation of small trees (the default)
     int variant = ptd::kDefaultVariant;   // render kernel variant (render_megakernel.hip)
     bool variant_auto = true;             // until pt_set_tuning picks one: chosen per scene size in pt_set_scene
     uint32_t* d_queue = nullptr;              // 8 shard heads
@@ -541,7 +541,7 @@ static int set_tuning_one(pt_ctx* c, int blocks_per_cu, int variant)
 static int set_build_mode_one(pt_ctx* c, int mode)
 {
     if (!c) return fail(nullptr, "pt_set_build_mode: null context");
-    if (mode != 0 && mode != 1) return fail(c, "pt_set_build_mode: 0 = Karras LBVH, 1 = PLOC");
+    if (mode != 0 && mode != 1 && mode != 2) return fail(c, "pt_set_build_mode: 0 = Karras LBVH, 1 = PLOC, 2 = PLOC + insertion-based optimisation (small scenes)");
     c->build_mode = mode;
     return 0;
 }

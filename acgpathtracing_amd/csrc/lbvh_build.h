@@ -37,7 +37,9 @@ struct LbvhResult {
     uint32_t   n_tris = 0, n_nodes = 0, max_depth = 0;
     float      scene_lo[3] = {0, 0, 0}, scene_hi[3] = {0, 0, 0};
     float      build_ms = 0.0f;
-    int        mode = 0;               // 0 Karras radix tree, 1 PLOC
+    int        mode = 0;               // 0 Karras radix tree, 1 PLOC, 2 PLOC + insertion-based optimisation on the host (scenes up to 16 384 triangles; the default)
+    float      opt_area_before = 0.0f, opt_area_after = 0.0f, opt_ms = 0.0f;      // mode 2: sum of the inner nodes' surface areas before / after, host time
+    uint32_t   opt_passes = 0;
     uint32_t   build_iterations = 0;   // PLOC merge rounds
 };
 

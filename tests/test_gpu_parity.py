@@ -244,6 +244,30 @@ def test_karras_tree_gives_the_same_answers(gpu_state_factory, oracle):
     assert image_mse(acc, ref) < MSE_TOL
 
 
+def test_every_tree_builder_renders_the_same_bits(gpu_state_factory):
+    """Build mode 0 (Karras), 1 (PLOC), 2 (PLOC + insertion-based optimisation on the host, the default for small scenes): boxes only
+    prune, so image bits and ray counters are the same whatever the tree; the optimised tree is not deeper than the lane stacks allow
+    and has the smaller sum of inner-node areas to show for its 12 ms (fewer BVH-loop trips of the stats kernel)."""
+    L = _native.hip()
+    p = make_params(160, 96, 8, 8, True, True)
+    imgs, trips = {}, {}
+    for mode in (1, 2, 0):
+        state, obj = gpu_state_factory(SCENE_FULL, width=160, height=96, build_mode=mode)
+        info = pt.getBvhInfo(state)
+        assert info.max_depth < info.stack_entries <= 28, (mode, info.max_depth, info.stack_entries)
+        acc, fb, st = _gpu_render(state, p)
+        imgs[mode] = (acc, fb, (int(st[0].radiance_rays), int(st[0].shadow_rays), int(st[0].paths)))
+        assert L.pt_set_tuning(state.context, 0, 6) == 0          # the stats twin of the default loop: trips through the BVH loop
+        _, _, st6 = _gpu_render(state, p)
+        trips[mode] = int(st6[0].trav_wave_steps)
+        assert L.pt_set_tuning(state.context, 0, _DEFAULT_VARIANT) == 0
+    for mode in (2, 0):
+        assert np.array_equal(imgs[mode][0].view(np.uint32), imgs[1][0].view(np.uint32)) and np.array_equal(imgs[mode][1], imgs[1][1]), mode
+        assert imgs[mode][2] == imgs[1][2], mode
+    print("BVH-loop trips: Karras %d, PLOC %d, PLOC + insertion-based optimisation %d" % (trips[0], trips[1], trips[2]))
+    assert trips[2] < trips[1] < trips[0]
+
+
 def test_trace_any_bit_exact(full):
     state, obj, sc = full
     v, idx = scene_arrays(obj)
