@@ -374,6 +374,7 @@ __global__ void k_single_node(const float4* __restrict__ tri_lo, const float4* _
 // Karras tree, profiles/r01_bvh_quality.txt).  Deterministic: ties go to the lower index and node
 // numbers come from prefix sums, not atomics.  Node 0 is the root (numbers are handed out downwards).
 constexpr int kPlocRadius = 8;
+constexpr uint32_t kReinsertIterations = 12;     // parallel reinsertion (13): at most this many find / lock / apply / refit rounds
 constexpr uint32_t kDepthFirstTris = 50000;      // scenes above this many triangles get their nodes in depth-first order (6a): where the tree outgrows the caches
 
 struct Cluster {
@@ -941,6 +942,220 @@ static uint32_t optimize_tree_host(std::vector<BvhNode>& nodes, uint32_t n_tris,
     return (inner == (uint32_t)t.m && leaves == n_tris) ? height : 0u;      // 0: the tree lost a node (a bug): the caller keeps the unoptimised one
 }
 
+// --- 13. parallel reinsertion on the device (build mode 2, scenes above kOptimizeMaxTris) ---------------------------------------
+// The same optimisation for trees too large for one host thread (1.31 M triangles: 24 s there), after Meister & Bittner 2018
+// ("Parallel reinsertion for bounding volume hierarchy optimization"): every node looks — read only — for the place where moving
+// it, with its subtree, shrinks the tree most; moves whose paths through the tree (node up to the lowest common ancestor and down to
+// the target) do not touch are applied together, the larger gain winning a contested node; boxes are refitted; repeat.
+//   find   walk up from the node: at every ancestor A the node's side shrinks (gain: the parent disappears, the ancestors below A
+//          lose the node's box) and the subtree of A's OTHER child is searched depth first, stackless (parent links), for the
+//          target y that pays least: area(B u y) for the new node + the growth of the nodes between A and y; pruned by the bound
+//          that what is left of the gain cannot beat the best found.
+//   lock   atomicMax of (gain, node) on every node of the path, incl. the grandparent whose child pointer changes.
+//   apply  the moves that hold all their locks: the sibling takes the parent's place, the parent becomes the new node (y, x) where y was.
+//   refit  bottom-up from the leaves, the second arrival at a node proceeds.
+// Unified node ids: inner nodes 0 .. m-1 (root 0, never moved), leaf slot s = m + s.  Deterministic (the maximum key is unique).
+struct ReinsTree {
+    int* parent;        // [m + n]
+    int2* child;        // [m] unified ids
+    float4* lo;         // [m + n]
+    float4* hi;
+    uint32_t m, n;
+};
+__device__ __forceinline__ float ri_area(const float4& l, const float4& h) { const float x = h.x - l.x, y = h.y - l.y, z = h.z - l.z; return x * y + y * z + z * x; }
+__device__ __forceinline__ float ri_union_area(const float4& l, const float4& h, const float4& bl, const float4& bh)
+{
+    const float x = fmaxf(h.x, bh.x) - fminf(l.x, bl.x), y = fmaxf(h.y, bh.y) - fminf(l.y, bl.y), z = fmaxf(h.z, bh.z) - fminf(l.z, bl.z);
+    return x * y + y * z + z * x;
+}
+__global__ void k_ri_init(const BvhNode* __restrict__ nodes, ReinsTree t)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.m) return;
+    const BvhNode nd = nodes[i];
+    // child 0: lo (a.x a.y a.z) hi (a.w b.x b.y); child 1: lo (b.z b.w c.x) hi (c.y c.z c.w)
+    const int c0 = nd.d.x >= 0 ? nd.d.x : (int)t.m + ~nd.d.x, c1 = nd.d.y >= 0 ? nd.d.y : (int)t.m + ~nd.d.y;
+    t.child[i] = make_int2(c0, c1);
+    t.parent[c0] = (int)i; t.parent[c1] = (int)i;
+    t.lo[c0] = make_float4(nd.a.x, nd.a.y, nd.a.z, 0.0f); t.hi[c0] = make_float4(nd.a.w, nd.b.x, nd.b.y, 0.0f);
+    t.lo[c1] = make_float4(nd.b.z, nd.b.w, nd.c.x, 0.0f); t.hi[c1] = make_float4(nd.c.y, nd.c.z, nd.c.w, 0.0f);
+    if (i == 0u) {
+        t.parent[0] = -1;
+        t.lo[0] = make_float4(fminf(nd.a.x, nd.b.z), fminf(nd.a.y, nd.b.w), fminf(nd.a.z, nd.c.x), 0.0f);
+        t.hi[0] = make_float4(fmaxf(nd.a.w, nd.c.y), fmaxf(nd.b.x, nd.c.z), fmaxf(nd.b.y, nd.c.w), 0.0f);
+    }
+}
+// best move of node x: target[x] = y (or -1), pivot[x] = the lowest common ancestor of the move, gain[x]
+__global__ void k_ri_find(ReinsTree t, int* __restrict__ target, int* __restrict__ pivot_out, float* __restrict__ gain_out)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= t.m + t.n) return;
+    target[x] = -1; gain_out[x] = 0.0f; pivot_out[x] = -1;
+    if (x == 0u) return;
+    const int p = t.parent[x];
+    if (p <= 0) return;                                  // children of the root stay: the root keeps its number
+    const float4 bl = t.lo[x], bh = t.hi[x];
+    const float ab = ri_area(bl, bh);
+    float best = 0.0f; int best_y = -1, best_pivot = -1;
+    const int2 pc = t.child[p];
+    int sib = pc.x == (int)x ? pc.y : pc.x;
+    float4 wl = t.lo[sib], wh = t.hi[sib];               // box of the subtree that takes p's place
+    float gain = ri_area(t.lo[p], t.hi[p]);              // p disappears
+    int cur = p, other = sib, piv = p;
+    for (int level = 0; level < 64; level++) {
+        // depth-first, stackless, over the subtree of `other`; induced = growth of the nodes from `other` down to the parent of `node`
+        int node = other;
+        float induced = 0.0f;
+        bool down = true;
+        for (int guard = 0; guard < (1 << 20); guard++) {
+            if (down) {
+                const float4 nl = t.lo[node], nh = t.hi[node];
+                const float direct = ri_union_area(nl, nh, bl, bh);
+                const float g = gain - induced - direct;
+                if (g > best && !(piv == p && node == sib)) { best = g; best_y = node; best_pivot = piv; }
+                const float growth = direct - ri_area(nl, nh);
+                if (node < (int)t.m && gain - (induced + growth) - ab > best) { induced += growth; node = t.child[node].x; }
+                else down = false;
+            }
+            if (!down) {
+                if (node == other) break;
+                const int par = t.parent[node];
+                const int2 cc = t.child[par];
+                if (cc.x == node) { node = cc.y; down = true; }
+                else {
+                    induced -= ri_union_area(t.lo[par], t.hi[par], bl, bh) - ri_area(t.lo[par], t.hi[par]);
+                    if (induced < 0.0f) induced = 0.0f;
+                    node = par;
+                }
+            }
+        }
+        // one level up: the parent of `cur` becomes the pivot.  `cur` then lies strictly between p and the pivot and shrinks to its box without
+        // x (wl, wh) — unless it is p itself, which is gone altogether and already counted
+        const int a = t.parent[cur];
+        if (a < 0) break;
+        if (cur != p) gain += ri_area(t.lo[cur], t.hi[cur]) - ri_area(wl, wh);
+        const int2 ac = t.child[a];
+        other = ac.x == cur ? ac.y : ac.x;
+        {   // the box of `a` without x, for when `a` itself lies below a later pivot
+            const float4 ol = t.lo[other], oh = t.hi[other];
+            wl = make_float4(fminf(wl.x, ol.x), fminf(wl.y, ol.y), fminf(wl.z, ol.z), 0.0f);
+            wh = make_float4(fmaxf(wh.x, oh.x), fmaxf(wh.y, oh.y), fmaxf(wh.z, oh.z), 0.0f);
+        }
+        cur = a; piv = a;
+        if (gain - ab <= best) break;                    // even a free insertion further up could not beat the best found
+    }
+    if (best_y >= 0 && best > 0.0f) { target[x] = best_y; pivot_out[x] = best_pivot; gain_out[x] = best; }
+}
+
+// What two moves must not share.  A move EDITS six nodes — x, its parent p (which becomes the new node), p's parent g and x's sibling (the
+// sibling takes p's place), the target y and y's parent — and it INSERTS THROUGH the nodes between y's parent and the pivot (their
+// boxes grow; nothing is written to them).  Two moves with disjoint edit sets write disjoint words.  A cycle — x under x' and x' under x
+// — needs each of the two moved roots to lie on the other's insertion path, so a move also loses against a stronger one that inserts
+// through a node it edits, and against a stronger one that edits a node it inserts through.  Two lock words per node (atomicMax of
+// (gain, node)): `edit` and `through`.  Far fewer conflicts than locking the whole path from x over the pivot to y (what the first
+// version did: 30 k moves of 2.6 M nodes in the first round on 1.31 M triangles).
+struct RiEdit { int n[6]; };
+__device__ __forceinline__ RiEdit ri_edit_set(const ReinsTree& t, int x, int y)
+{
+    RiEdit e;
+    const int p = t.parent[x];
+    const int2 pc = t.child[p];
+    e.n[0] = x; e.n[1] = p; e.n[2] = t.parent[p]; e.n[3] = pc.x == x ? pc.y : pc.x; e.n[4] = y; e.n[5] = t.parent[y];
+    return e;
+}
+template <typename F>
+__device__ __forceinline__ void ri_for_through(const ReinsTree& t, int y, int pivot, F f)
+{
+    int guard = 0;          // (at most the tree's height; the bound turns a corrupted tree into a wrong result instead of a hang)
+    for (int a = t.parent[y]; a != pivot && a >= 0 && guard < 4096; a = t.parent[a], guard++) f(a);
+}
+__global__ void k_ri_lock(ReinsTree t, const int* __restrict__ target, const int* __restrict__ pivot, const float* __restrict__ gain,
+                          unsigned long long* __restrict__ lock_edit, unsigned long long* __restrict__ lock_through)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= t.m + t.n || target[x] < 0) return;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(gain[x]) << 32) | x;       // gains are positive: their bits order as they do
+    const RiEdit e = ri_edit_set(t, (int)x, target[x]);
+#pragma unroll
+    for (int k = 0; k < 6; k++) if (e.n[k] >= 0) atomicMax(&lock_edit[e.n[k]], key);
+    ri_for_through(t, target[x], pivot[x], [&](int a) { atomicMax(&lock_through[a], key); });
+}
+__global__ void k_ri_check(ReinsTree t, const int* __restrict__ target, const int* __restrict__ pivot, const float* __restrict__ gain,
+                           const unsigned long long* __restrict__ lock_edit, const unsigned long long* __restrict__ lock_through,
+                           uint32_t* __restrict__ winner, uint32_t* __restrict__ n_winners)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= t.m + t.n) return;
+    winner[x] = 0u;
+    if (target[x] < 0) return;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(gain[x]) << 32) | x;
+    const RiEdit e = ri_edit_set(t, (int)x, target[x]);
+    bool all = true;
+#pragma unroll
+    for (int k = 0; k < 6; k++) if (e.n[k] >= 0) all = all && lock_edit[e.n[k]] == key && lock_through[e.n[k]] <= key;
+    ri_for_through(t, target[x], pivot[x], [&](int a) { all = all && lock_edit[a] <= key; });
+    if (all) { winner[x] = 1u; atomicAdd(n_winners, 1u); }
+}
+// the moves that hold all their locks; every node they write is theirs alone (k_ri_check read the tree before any of this)
+__global__ void k_ri_apply(ReinsTree t, const int* __restrict__ target, const uint32_t* __restrict__ winner)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= t.m + t.n || winner[x] == 0u) return;
+    const int y = target[x];
+    const int p = t.parent[x];
+    const int g = t.parent[p];
+    const int2 pc = t.child[p];
+    const int sib = pc.x == (int)x ? pc.y : pc.x;
+    // the sibling takes p's place under g
+    int2 gc = t.child[g];
+    if (gc.x == p) gc.x = sib; else gc.y = sib;
+    t.child[g] = gc;
+    t.parent[sib] = g;
+    // p becomes the new node (y, x) where y was (y's parent is read AFTER the step above: it may be g)
+    const int yp = t.parent[y];
+    int2 yc = t.child[yp];
+    if (yc.x == y) yc.x = p; else yc.y = p;
+    t.child[yp] = yc;
+    t.parent[p] = yp;
+    t.child[p] = make_int2(y, (int)x);
+    t.parent[y] = p;
+}
+__global__ void k_ri_refit(ReinsTree t, uint32_t* __restrict__ visit)
+{
+    const uint32_t leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (leaf >= t.n) return;
+    int cur = t.parent[t.m + leaf];
+    for (int guard = 0; cur >= 0 && guard < 4096; guard++) {
+        const uint32_t prev = __hip_atomic_fetch_add(&visit[cur], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == 0u) return;
+        const int2 c = t.child[cur];
+        const float4 l0 = t.lo[c.x], h0 = t.hi[c.x], l1 = t.lo[c.y], h1 = t.hi[c.y];
+        t.lo[cur] = make_float4(fminf(l0.x, l1.x), fminf(l0.y, l1.y), fminf(l0.z, l1.z), 0.0f);
+        t.hi[cur] = make_float4(fmaxf(h0.x, h1.x), fmaxf(h0.y, h1.y), fmaxf(h0.z, h1.z), fmaxf(h0.w, h1.w) + 1.0f);     // .w of hi: height (0 for a leaf)
+        cur = t.parent[cur];
+    }
+}
+__global__ void k_ri_area(ReinsTree t, double* __restrict__ sum)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    double a = i < t.m ? (double)ri_area(t.lo[i], t.hi[i]) : 0.0;
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+    if ((threadIdx.x & 63) == 0 && a != 0.0) atomicAdd(sum, a);
+}
+__global__ void k_ri_write(ReinsTree t, BvhNode* __restrict__ nodes)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.m) return;
+    const int2 c = t.child[i];
+    const float4 l0 = t.lo[c.x], h0 = t.hi[c.x], l1 = t.lo[c.y], h1 = t.hi[c.y];
+    BvhNode nd;
+    nd.a = make_float4(l0.x, l0.y, l0.z, h0.x);
+    nd.b = make_float4(h0.y, h0.z, l1.x, l1.y);
+    nd.c = make_float4(l1.z, h1.x, h1.y, h1.z);
+    nd.d = make_int4(c.x < (int)t.m ? c.x : ~(c.x - (int)t.m), c.y < (int)t.m ? c.y : ~(c.y - (int)t.m), 0, 0);
+    nodes[i] = nd;
+}
+
 static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t* h_idx, uint32_t n,
                        const uint32_t* h_mat_ids, int mode, hipStream_t stream, LbvhResult& out, std::string& err)
 {
@@ -1049,7 +1264,8 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
     }
     HIPCK(hipGetLastError());
     uint32_t opt_height = 0;
-    if (mode == 2 && n > 2 && n <= kOptimizeMaxTris) {        // small scenes: insertion-based optimisation of the PLOC tree (12), on the host
+    const uint32_t opt_max_host = kOptimizeMaxTris;
+    if (mode == 2 && n > 2 && n <= opt_max_host) {        // small scenes: insertion-based optimisation of the PLOC tree (12), on the host
         const auto t0 = std::chrono::steady_clock::now();
         std::vector<BvhNode> h_nodes(n_nodes);
         HIPCK(hipMemcpyAsync(h_nodes.data(), out.nodes, (size_t)n_nodes * sizeof(BvhNode), hipMemcpyDeviceToHost, stream));
@@ -1070,6 +1286,73 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
         if (getenv("ACGPT_DEBUG_BUILD"))
             fprintf(stderr, "[acgpt build] insertion-based optimisation: %d passes, inner-node area sum %.6g -> %.6g (%.1f %%), height %u, %.1f ms on the host\n",
                     passes, a0, a1, 100.0 * a1 / (a0 > 0.0 ? a0 : 1.0), opt_height, out.opt_ms);
+    }
+    if (mode == 2 && n > opt_max_host && n_nodes > 2) {       // larger scenes: parallel reinsertion on the device (13)
+        ReinsTree t;
+        t.m = n_nodes; t.n = n;
+        const size_t N = (size_t)n_nodes + n;
+        int *d_target, *d_pivot; float* d_gain; unsigned long long *d_lock, *d_lock_w; uint32_t *d_win, *d_nwin, *d_rvisit; double* d_area;
+        HIPCK(sc.alloc(&t.parent, N * 4));
+        HIPCK(sc.alloc(&t.child, (size_t)n_nodes * 8));
+        HIPCK(sc.alloc(&t.lo, N * 16));
+        HIPCK(sc.alloc(&t.hi, N * 16));
+        HIPCK(sc.alloc(&d_target, N * 4));
+        HIPCK(sc.alloc(&d_pivot, N * 4));
+        HIPCK(sc.alloc(&d_gain, N * 4));
+        HIPCK(sc.alloc(&d_lock, N * 8));
+        HIPCK(sc.alloc(&d_lock_w, N * 8));
+        HIPCK(sc.alloc(&d_win, N * 4));
+        HIPCK(sc.alloc(&d_nwin, 4));
+        HIPCK(sc.alloc(&d_rvisit, (size_t)n_nodes * 4));
+        HIPCK(sc.alloc(&d_area, 8));
+        const uint32_t nbm = (n_nodes + 255) / 256, nbn = (uint32_t)((N + 255) / 256);
+        const auto t0 = std::chrono::steady_clock::now();
+        k_ri_init<<<nbm, 256, 0, stream>>>(out.nodes, t);
+        const auto area_now = [&](double& a) -> hipError_t {
+            hipError_t e = hipMemsetAsync(d_area, 0, 8, stream);
+            if (e != hipSuccess) return e;
+            k_ri_area<<<nbm, 256, 0, stream>>>(t, d_area);
+            e = hipMemcpyAsync(&a, d_area, 8, hipMemcpyDeviceToHost, stream);
+            return e == hipSuccess ? hipStreamSynchronize(stream) : e;
+        };
+        // (the first refit also gives every inner node its box: k_ri_init only knows the children's)
+        HIPCK(hipMemsetAsync(d_rvisit, 0, (size_t)n_nodes * 4, stream));
+        k_ri_refit<<<blocks, 256, 0, stream>>>(t, d_rvisit);
+        double a_first = 0.0, a_prev = 0.0, a_now = 0.0;
+        HIPCK(area_now(a_first));
+        a_prev = a_first;
+        uint32_t iters = 0, moved = 0;
+        const uint32_t max_it = getenv("ACGPT_RI_ITERS") ? (uint32_t)atoi(getenv("ACGPT_RI_ITERS")) : kReinsertIterations;
+        const double stop_at = getenv("ACGPT_RI_STOP") ? atof(getenv("ACGPT_RI_STOP")) : 0.998;
+        for (; iters < max_it; iters++) {
+            uint32_t winners = 0;
+            k_ri_find<<<nbn, 256, 0, stream>>>(t, d_target, d_pivot, d_gain);
+            HIPCK(hipMemsetAsync(d_lock, 0, N * 8, stream));
+            HIPCK(hipMemsetAsync(d_lock_w, 0, N * 8, stream));
+            HIPCK(hipMemsetAsync(d_nwin, 0, 4, stream));
+            k_ri_lock<<<nbn, 256, 0, stream>>>(t, d_target, d_pivot, d_gain, d_lock, d_lock_w);
+            k_ri_check<<<nbn, 256, 0, stream>>>(t, d_target, d_pivot, d_gain, d_lock, d_lock_w, d_win, d_nwin);
+            k_ri_apply<<<nbn, 256, 0, stream>>>(t, d_target, d_win);
+            HIPCK(hipMemsetAsync(d_rvisit, 0, (size_t)n_nodes * 4, stream));
+            k_ri_refit<<<blocks, 256, 0, stream>>>(t, d_rvisit);
+            HIPCK(hipGetLastError());
+            HIPCK(hipMemcpyAsync(&winners, d_nwin, 4, hipMemcpyDeviceToHost, stream));
+            HIPCK(area_now(a_now));
+            moved += winners;
+            if (getenv("ACGPT_DEBUG_BUILD"))
+                fprintf(stderr, "[acgpt build] parallel reinsertion, iteration %u: %u moves, inner-node area sum %.6g (%.2f %% of the PLOC tree's)\n", iters + 1, winners, a_now, 100.0 * a_now / (a_first > 0.0 ? a_first : 1.0));
+            if (winners == 0u || !(a_now < a_prev * stop_at)) { iters++; break; }
+            a_prev = a_now;
+        }
+        k_ri_write<<<nbm, 256, 0, stream>>>(t, out.nodes);
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(&root_hi, t.hi, 16, hipMemcpyDeviceToHost, stream));      // the root's height after the last refit
+        HIPCK(hipStreamSynchronize(stream));
+        opt_height = (uint32_t)root_hi.w;
+        out.opt_area_before = (float)a_first; out.opt_area_after = (float)a_now; out.opt_passes = iters;
+        out.opt_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (getenv("ACGPT_DEBUG_BUILD"))
+            fprintf(stderr, "[acgpt build] parallel reinsertion: %u iterations, %u moves, height %u, %.1f ms\n", iters, moved, opt_height, out.opt_ms);
     }
     if (n > kDepthFirstTris) {         // large scenes: the nodes in depth-first order (6a)
         int* d_par; uint32_t *d_size, *d_new; BvhNode* d_sorted = nullptr;
