@@ -167,10 +167,12 @@ int      pt_set_scene(pt_ctx* ctx,
                       const pt_material* mats, size_t n_mats);
 /* Hierarchy builder used by the NEXT pt_set_scene: all start from the same on-device Morton radix
  * sort; 0 = Karras radix tree (classic LBVH), 1 = PLOC (locally-ordered clustering: fewer node visits
- * per ray), 2 = PLOC followed, for scenes up to 16 384 triangles, by an insertion-based optimisation
- * of the tree on the host (Bittner et al. 2013; 12 ms for the 1 264 triangles of the Cornell scenes,
- * 2.5 % fewer visits) — the default; larger scenes get the PLOC tree as it is, its nodes in depth-first
- * order.  Results of every query and every image bit are identical, only speed differs.          */
+ * per ray), 2 = PLOC followed by an insertion-based optimisation of the tree — the default: for scenes
+ * up to 16 384 triangles on the host, one node at a time (Bittner et al. 2013; 12 ms for the 1 264
+ * triangles of the Cornell scenes, 2.5 % fewer visits), for larger ones on the device, all nodes at
+ * once (parallel reinsertion, Meister & Bittner 2018; +73 ms at 1.31 M triangles, +0.6 s at 10.5 M,
+ * render 6 % / 13 % faster); scenes above 50 000 triangles get their nodes in depth-first order.
+ * Results of every query and every image bit are identical, only speed differs.                  */
 int      pt_set_build_mode(pt_ctx* ctx, int mode);
 uint64_t pt_scene_handle(pt_ctx* ctx);
 int      pt_get_bvh_info(pt_ctx* ctx, pt_bvh_info* out);
