@@ -951,7 +951,7 @@ static uint32_t optimize_tree_host(std::vector<BvhNode>& nodes, uint32_t n_tris,
 //          lose the node's box) and the subtree of A's OTHER child is searched depth first, stackless (parent links), for the
 //          target y that pays least: area(B u y) for the new node + the growth of the nodes between A and y; pruned by the bound
 //          that what is left of the gain cannot beat the best found.
-//   lock   atomicMax of (gain, node): an `edit` word on the six nodes the move rewrites, a `through` word on the nodes it only grows (below).
+//   lock   atomicMax of (gain, node) on every node of the path, incl. the grandparent whose child pointer changes.
 //   apply  the moves that hold all their locks: the sibling takes the parent's place, the parent becomes the new node (y, x) where y was.
 //   refit  bottom-up from the leaves, the second arrival at a node proceeds.
 // Unified node ids: inner nodes 0 .. m-1 (root 0, never moved), leaf slot s = m + s.  Deterministic (the maximum key is unique).
