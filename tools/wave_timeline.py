@@ -26,10 +26,12 @@ def main():
     ap.add_argument("--chunks", type=int, default=0)
     ap.add_argument("--partition", default="0,1")
     ap.add_argument("--variant", type=int, default=6)
+    ap.add_argument("--direct-lighting", type=int, default=1)
+    ap.add_argument("--importance-sampling", type=int, default=1)
     a = ap.parse_args()
     L = _native.hip()
-    state, obj = pt.setup(os.path.join(pt.SCENES, a.scene), width=a.width, height=a.height, max_depth=a.max_depth, direct_lighting=True, importance_sampling=True, spp=a.spp)
-    p = make_params(a.width, a.height, a.spp, a.max_depth, True, True)
+    state, obj = pt.setup(os.path.join(pt.SCENES, a.scene), width=a.width, height=a.height, max_depth=a.max_depth, direct_lighting=bool(a.direct_lighting), importance_sampling=bool(a.importance_sampling), spp=a.spp)
+    p = make_params(a.width, a.height, a.spp, a.max_depth, bool(a.direct_lighting), bool(a.importance_sampling))
     keep_a, keep_h = state.params.accumulationBuffer, state.params.handle
     C.memmove(C.byref(state.params), C.byref(p), C.sizeof(p))
     state.params.accumulationBuffer, state.params.handle = keep_a, keep_h
