@@ -541,7 +541,7 @@ static int set_tuning_one(pt_ctx* c, int blocks_per_cu, int variant)
 static int set_build_mode_one(pt_ctx* c, int mode)
 {
     if (!c) return fail(nullptr, "pt_set_build_mode: null context");
-    if (mode != 0 && mode != 1 && mode != 2) return fail(c, "pt_set_build_mode: 0 = Karras LBVH, 1 = PLOC, 2 = PLOC + insertion-based optimisation (small scenes)");
+    if (mode != 0 && mode != 1 && mode != 2) return fail(c, "pt_set_build_mode: 0 = Karras LBVH, 1 = PLOC, 2 = PLOC + insertion-based optimisation");
     c->build_mode = mode;
     return 0;
 }
@@ -921,7 +921,7 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
     static const uint32_t grant_on_l2[6] = {32u, 64u, 128u, 256u, 256u, 256u};
     static const uint32_t grant_beyond_l2[6] = {16u, 16u, 32u, 64u, 64u, 64u};
     const size_t scene_bytes = (size_t)c->bvh.n_nodes * sizeof(ptd::HNode) + (size_t)c->bvh.n_tris * sizeof(ptd::TriRecord);
-    a.grant = (scene_bytes <= ((size_t)4 << 20) ? grant_on_l2 : grant_beyond_l2)[a.chunk_shift];
+    a.grant = (scene_bytes <= ((size_t)4 << 20) ? grant_on_l2 : grant_beyond_l2)[a.chunk_shift];      // (capped for small launches once the grid is known, below)
     a.chunk_spp = p->samplesPerPixel >> a.chunk_shift;
     a.n_frames = n_frames;
     a.sub_shift = a.chunk_shift;
@@ -1015,6 +1015,16 @@ static int launch_batch(pt_ctx* c, const pt_params* p, uint32_t n_frames)
     const uint32_t blocks_needed = (waves_needed + wpb - 1) / wpb;
     if (grid > blocks_needed) grid = blocks_needed;
     if (grid < 1) grid = 1;
+    {   // a small launch wants small grants: a wave that has fetched its last grant works it off alone, so the launch ends one grant's
+        // worth of work after the queue is empty.  The reference's own start-up workload in one launch (512 x 512 x 128 spp: 4.2 M items,
+        // 820 per wave) with grants of 256 had a third of the items handed out in the first 60 us and its last wave finishing 1.9 ms after the
+        // median one (5.2 ms a launch where eight fused steps take 2.8 each, profiles/r04_wave_timeline_c0.txt): keep >= 16 grants per wave.
+        const uint32_t per_wave = a.total_samples / (grid * wpb);
+        uint32_t cap = 1u << a.chunk_shift;                         // never below one (pixel, sub-frame) group
+        while (cap * 2u * 16u <= per_wave) cap *= 2u;
+        if (const char* e = getenv("ACGPT_GRANT")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 1u && v <= (64u << a.chunk_shift)) { a.grant = v; cap = v; } }     // sweeps (a grant is decoded by 64 lanes, one group each: <= 64 groups)
+        if (a.grant > cap) a.grant = cap;
+    }
 
     if (a.chunk_shift) {   // fold slots for every wave of the grid
         const size_t need = (size_t)grid * wpb * ((size_t)ptd::kRenderFoldSlots << a.chunk_shift) * 3 * sizeof(float);

@@ -7,6 +7,7 @@ BASELINE.json's north_star does: per-channel L2 (MSE over clamped linear radianc
 sinf/cosf/acosf/powf are ROCm's, the oracle's are glibc's, so single paths can flip.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -489,7 +490,16 @@ def test_queue_order_and_pixel_classes_change_no_bit(diffuse, both_modes):
                 if classes:        # whole pixels settled without a cull test: never fewer than the per-ray test finds
                     assert int(st[0].culled_rays) >= ref[3] - 16 * 2 * 4 * 360
         assert L.pt_debug_queue_order(state.context, 4) != 0
+        # how many items a wave takes per queue atomic (capped for small launches so that every wave fetches >= 16 grants,
+        # profiles/r04_wave_timeline_c0.txt; ACGPT_GRANT overrides the rule): one group, the rule's choice, far more than a wave's share
+        L.pt_debug_pixel_classes(state.context, 1); L.pt_debug_queue_order(state.context, 1)
+        for grant in ("4", "64", "256", "1024"):           # 256 = 64 groups of 4 runs, the most a grant can hold; 1024 is refused (the rule stays)
+            os.environ["ACGPT_GRANT"] = grant
+            acc, fb, st = _gpu_render(state, p, frames=2, fuse=2)
+            cnt = (int(st[0].radiance_rays), int(st[0].shadow_rays), int(st[0].paths), int(st[0].pixels))
+            assert np.array_equal(acc.view(np.uint32), ref[0].view(np.uint32)) and np.array_equal(fb, ref[1]) and cnt == ref[2], grant
     finally:
+        os.environ.pop("ACGPT_GRANT", None)
         L.pt_debug_pixel_classes(state.context, 1); L.pt_debug_queue_order(state.context, 1)
         L.pt_set_sample_chunks(state.context, 1)
 
