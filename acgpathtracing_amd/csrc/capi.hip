@@ -1275,12 +1275,17 @@ PT_API int pt_debug_window_moves(pt_ctx* c, uint64_t* out)
 
 #ifdef ACGPT_EXPERIMENTS
 // experiments build only: renumber the resident fp16 nodes (0: the build's order, 1: sibling pairs share a 64-byte line, 2: depth first)
+namespace ptd { bool reorder_records_dfs(LbvhResult& r, hipStream_t stream, std::string& err); }      // lbvh_experiments.inc
 PT_API int pt_debug_node_order(pt_ctx* c, int mode)
 {
-    if (!c || mode < 0 || mode > 2) return fail(c, "pt_debug_node_order: mode 0, 1 or 2");
+    if (!c || mode < 0 || mode > 3) return fail(c, "pt_debug_node_order: mode 0, 1, 2 or 3");
     CK(c, hipSetDevice(c->device));
     CK(c, hipStreamSynchronize(c->stream));
     std::string err;
+    if (mode == 3) {        // the triangle records in depth-first leaf order (in place; the nodes stay as they are)
+        if (!ptd::reorder_records_dfs(c->bvh, c->stream, err)) return fail(c, "pt_debug_node_order: " + err);
+        return 0;
+    }
     if (!ptd::reorder_hcnodes(c->bvh, mode, c->stream, err)) return fail(c, "pt_debug_node_order: " + err);
     return 0;
 }
