@@ -1196,10 +1196,10 @@ PT_API int pt_bench_traversal(pt_ctx* c, const float* rays, size_t n, int repeat
 // in / out sizes per element, in dwords (op 1: in = {seed, count}, out = 2 * count)
 PT_API int pt_selftest(pt_ctx* c, int op, const void* in, size_t n, void* out)
 {
-    //                            0  1  2   3   4   5   6   7   8  9 10 11 12 13 14 15 16 17 18  19  20 .. 29 unused           30 31 32 33 34 35 36 37 38  39  40
-    static const int in_dw[41] = {2, 2, 3, 10, 10, 10, 10, 10, 10, 7, 4, 1, 6, 4, 2, 2, 6, 7, 3, 17, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 1, 6, 4, 2, 2, 6, 7, 3, 20, 17},
-                     out_dw[41] = {1, 0, 1, 3, 3, 3, 3, 3, 3, 4, 2, 4, 3, 3, 3, 3, 3, 3, 1, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 3, 3, 3, 3, 3, 3, 1, 3, 3};
-    if (!c || !in || !out || op < 0 || op > 40 || in_dw[op] == 0 || n == 0 || n > (1u << 24)) return fail(c, "pt_selftest: bad argument");
+    //                            0  1  2   3   4   5   6   7   8  9 10 11 12 13 14 15 16 17 18  19  20 .. 29 unused           30 31 32 33 34 35 36 37 38  39  40  41
+    static const int in_dw[42] = {2, 2, 3, 10, 10, 10, 10, 10, 10, 7, 4, 1, 6, 4, 2, 2, 6, 7, 3, 17, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 1, 6, 4, 2, 2, 6, 7, 3, 20, 17, 19},
+                     out_dw[42] = {1, 0, 1, 3, 3, 3, 3, 3, 3, 4, 2, 4, 3, 3, 3, 3, 3, 3, 1, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 3, 3, 3, 3, 3, 3, 1, 3, 3, 3};
+    if (!c || !in || !out || op < 0 || op > 41 || in_dw[op] == 0 || n == 0 || n > (1u << 24)) return fail(c, "pt_selftest: bad argument");
     CK(c, hipSetDevice(c->device));
     size_t in_bytes = n * (size_t)in_dw[op] * 4, out_bytes = n * (size_t)out_dw[op] * 4;
     uint32_t launch_n = (uint32_t)n;

@@ -18,7 +18,7 @@ struct LbvhResult {
     float      pad_abs = 0.0f;         // absolute pad of the triangle boxes (record_aabb): 2^-19 of the scene's largest |coordinate|
     HNode*     top_nodes = nullptr;    // device, kTopNodesMax: the first n_top inner nodes breadth first (children inside the array: kTopNodeFlag | position)
     uint32_t   n_top = 0;
-    HSpace     hspace = {0, 0, 0, 1};
+    HSpace     hspace = {0, 0, 0, 1, 1, 1, 1, 0};
     float      half_area_ratio = 0.0f; // sum of child-box areas after fp16 outward rounding / before (what a random ray pays)
     float      half_box_inflation = 0.0f; // mean over the child boxes of their own area after / before (what a ray through the finest geometry pays)
     QGrid      grid = {};              // world -> grid transform of qnodes

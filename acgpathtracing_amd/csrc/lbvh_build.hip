@@ -651,12 +651,12 @@ __global__ void k_hc_nodes(const BvhNode* __restrict__ nodes, uint32_t n, HSpace
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const BvhNode nd = nodes[i];
-    const float scale = 1.0f / sp.inv_scale;
+    const float sx = 1.0f / sp.isx, sy = 1.0f / sp.isy, sz = 1.0f / sp.isz;
     HNode o;
     // child 0: lo (a.x a.y a.z) hi (a.w b.x b.y); child 1: lo (b.z b.w c.x) hi (c.y c.z c.w)
-    o.a = make_uint4(pack_centre_half(nd.a.x, nd.a.w, sp.cx, scale), pack_centre_half(nd.a.y, nd.b.x, sp.cy, scale), pack_centre_half(nd.a.z, nd.b.y, sp.cz, scale),
+    o.a = make_uint4(pack_centre_half(nd.a.x, nd.a.w, sp.cx, sx), pack_centre_half(nd.a.y, nd.b.x, sp.cy, sy), pack_centre_half(nd.a.z, nd.b.y, sp.cz, sz),
                      nd.d.x >= 0 ? (uint32_t)nd.d.x << 5 : (uint32_t)nd.d.x);
-    o.b = make_uint4(pack_centre_half(nd.b.z, nd.c.y, sp.cx, scale), pack_centre_half(nd.b.w, nd.c.z, sp.cy, scale), pack_centre_half(nd.c.x, nd.c.w, sp.cz, scale),
+    o.b = make_uint4(pack_centre_half(nd.b.z, nd.c.y, sp.cx, sx), pack_centre_half(nd.b.w, nd.c.z, sp.cy, sy), pack_centre_half(nd.c.x, nd.c.w, sp.cz, sz),
                      nd.d.y >= 0 ? (uint32_t)nd.d.y << 5 : (uint32_t)nd.d.y);
     hn[i] = o;
 }
@@ -951,7 +951,7 @@ static uint32_t optimize_tree_host(std::vector<BvhNode>& nodes, uint32_t n_tris,
 //          lose the node's box) and the subtree of A's OTHER child is searched depth first, stackless (parent links), for the
 //          target y that pays least: area(B u y) for the new node + the growth of the nodes between A and y; pruned by the bound
 //          that what is left of the gain cannot beat the best found.
-//   lock   atomicMax of (gain, node) on every node of the path, incl. the grandparent whose child pointer changes.
+//   lock   atomicMax of (gain, node): an `edit` word on the six nodes the move rewrites, a `through` word on the nodes it only grows (below).
 //   apply  the moves that hold all their locks: the sibling takes the parent's place, the parent becomes the new node (y, x) where y was.
 //   refit  bottom-up from the leaves, the second arrival at a node proceeds.
 // Unified node ids: inner nodes 0 .. m-1 (root 0, never moved), leaf slot s = m + s.  Deterministic (the maximum key is unique).
@@ -1392,6 +1392,16 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
         // power of two: its reciprocal's rounding and the product's (2^-23 of a coordinate) sit inside pack_planes' 2^-18 guard
         // (test_gpu_fp16_slab_is_conservative runs both scales; profiles/r03_ab_hspace_scale.txt: -0.6 % / -0.3 % / 0 on configs 2 / 3 / 5).
         sp.inv_scale = (half_ext > 0.0f && half_ext < INFINITY ? half_ext : 1.0f) / 1023.0f;
+        {   // the {centre, half extent} nodes: a scale per axis, every face of the scene box at |g| = 1023 (pt_device.h pack_centre_half).  An axis
+            // the scene is (almost) flat on keeps at least 2^-20 of the longest extent; ACGPT_HC_UNIFORM=1: one scale for all (the A/B,
+            // profiles/r04_ab_axis_scales.txt)
+            float* is = &sp.isx;
+            for (int k = 0; k < 3; k++) {
+                const float hk = fmaxf(out.scene_hi[k] - cc[k], cc[k] - out.scene_lo[k]);
+                is[k] = (hk > half_ext * 0x1p-20f && hk < INFINITY && !getenv("ACGPT_HC_UNIFORM") ? hk : (half_ext > 0.0f && half_ext < INFINITY ? half_ext : 1.0f)) / 1023.0f;
+            }
+            sp.pad_ = 0.0f;
+        }
         float* d_area;
         float h_area[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         HIPCK(sc.alloc(&d_area, 16));

@@ -63,7 +63,8 @@ struct __attribute__((aligned(16))) HNode {
     uint4 b;
 };
 static_assert(sizeof(HNode) == 32, "hnode size");
-struct HSpace { float cx, cy, cz, inv_scale; };     // world = g * inv_scale + centre; the builder puts the scene's farthest plane at g = 1023
+struct HSpace { float cx, cy, cz, inv_scale;        // world = g * inv_scale + centre; the builder puts the scene's farthest plane at g = 1023
+                float isx, isy, isz, pad_; };       // the {centre, half extent} nodes (NODE_FMT 11) have a scale per axis: every face of the scene box at |g| = 1023 (below)
 
 // Shared-plane node (NODE_FMT 10, round 4), 16 B = ONE 16-byte load per visit.  A child box is its parent's box cut by new planes, and
 // because the parent's box is the union of its two children, each of the parent's six planes is inherited by at least one child: the two
@@ -331,7 +332,11 @@ __device__ __forceinline__ void slab_h9(uint32_t px, uint32_t py, uint32_t pz, c
 // rotated form's two v_fma_mix_f32 and half a v_alignbit_b32; but the subtract and the add are FULL-rate fp32 instructions, which the SIMD executes
 // beside a half-rate neighbour almost for nothing (profiles/r04_ubench_valu.txt: v_max_f32 + v_fma_f32 as a pair 4.7 cycles, alone 4.1 + 2.6),
 // while v_alignbit_b32 is one more half-rate instruction in a loop that is made of them.  No rotate flags in the multipliers either.
-// builder side: c rounded to nearest, h rounded up so that [c - h, c + h] holds the fp32 interval plus the same 2^-18 relative guard as pack_planes
+// builder side: c rounded to nearest, h rounded up so that [c - h, c + h] holds the fp32 interval plus the same 2^-18 relative guard as pack_planes.
+// A scale PER AXIS (HSpace isx / isy / isz; the ray parameter t does not care how an axis is scaled, the loop is unchanged): each face of the
+// scene box sits at |g| = 1023, an fp16 value, so a flat box on such a face — a wall of a closed room, and every inner box that touches it —
+// has c exact and h = its pad: as thin as the fp32 box, where a centre between two fp16 values makes it up to one step (1 / 2046 of the
+// extent) thick and every ray that leaves the wall stays inside it beyond tmin and tests the wall's triangles for nothing.
 __device__ __forceinline__ uint32_t pack_centre_half(float lo, float hi, float c0, float scale)
 {
     if (!(lo <= hi)) return half_bits(__float2half_rn(0.0f)) | (half_bits(__float2half_rn(-1.0f)) << 16);      // empty child: a negative half extent is never hit
@@ -346,7 +351,7 @@ __device__ __forceinline__ void setup_ray_hc(const f3& ro, const f3& rd, const H
 {
     const f3 r = mk(finite_rcp(rd.x), finite_rcp(rd.y), finite_rcp(rd.z));
     add = mk((HS.cx - ro.x) * r.x, (HS.cy - ro.y) * r.y, (HS.cz - ro.z) * r.z);
-    mul = r * HS.inv_scale;
+    mul = mk(r.x * HS.isx, r.y * HS.isy, r.z * HS.isz);
 }
 __device__ __forceinline__ void slab_hc(uint32_t px, uint32_t py, uint32_t pz, const f3& mul, const f3& add, float rtmin, float& tn, float& tf)
 {

@@ -121,7 +121,8 @@ __global__ void k_selftest(int op, const uint32_t* __restrict__ in, uint32_t n, 
     if (op == 40) {
         // op 19's records through the fp16 centre / half-extent form (NODE_FMT 11): pack_centre_half, setup_ray_hc, slab_hc
         const float* r = fin + 17 * i;
-        HSpace hs; hs.cx = r[12]; hs.cy = r[13]; hs.cz = r[14]; hs.inv_scale = r[15];
+        // (one scale on every axis here; op 41 takes a scale per axis, what the builder uses)
+        HSpace hs; hs.cx = r[12]; hs.cy = r[13]; hs.cz = r[14]; hs.inv_scale = r[15]; hs.isx = hs.isy = hs.isz = r[15]; hs.pad_ = 0.0f;
         const float scale = 1.0f / hs.inv_scale;
         const uint32_t px = pack_centre_half(r[6], r[9], hs.cx, scale), py = pack_centre_half(r[7], r[10], hs.cy, scale), pz = pack_centre_half(r[8], r[11], hs.cz, scale);
         f3 mul, add;
@@ -129,6 +130,18 @@ __global__ void k_selftest(int op, const uint32_t* __restrict__ in, uint32_t n, 
         float tn, tf;
         slab_hc(px, py, pz, mul, add, 0.01f, tn, tf);
         out[3 * i] = tn <= fminf(tf, r[16]) ? 1u : 0u; fout[3 * i + 1] = tn; fout[3 * i + 2] = tf;
+        return;
+    }
+    if (op == 41) {
+        // op 40 with a scale per axis: in = ray o xyz, d xyz, box lo xyz, hi xyz, scene centre xyz, inv_scale xyz, tmax (19 floats)
+        const float* r = fin + 19 * i;
+        HSpace hs; hs.cx = r[12]; hs.cy = r[13]; hs.cz = r[14]; hs.inv_scale = r[15]; hs.isx = r[15]; hs.isy = r[16]; hs.isz = r[17]; hs.pad_ = 0.0f;
+        const uint32_t px = pack_centre_half(r[6], r[9], hs.cx, 1.0f / hs.isx), py = pack_centre_half(r[7], r[10], hs.cy, 1.0f / hs.isy), pz = pack_centre_half(r[8], r[11], hs.cz, 1.0f / hs.isz);
+        f3 mul, add;
+        setup_ray_hc(mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5]), hs, mul, add);
+        float tn, tf;
+        slab_hc(px, py, pz, mul, add, 0.01f, tn, tf);
+        out[3 * i] = tn <= fminf(tf, r[18]) ? 1u : 0u; fout[3 * i + 1] = tn; fout[3 * i + 2] = tf;
         return;
     }
     if (op == 39) {

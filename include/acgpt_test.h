@@ -52,6 +52,7 @@ int pt_bench_traversal(pt_ctx* ctx, const float* rays, size_t n, int repeats, in
  *   op 31 sin / cos of 2 pi u                       in float[n]     out float[n][4] = v_sin_f32(u), v_cos_f32(u), sinf(2 pi u), cosf(2 pi u)
  *   op 32..38 = ops 12..18 at that level, same records (op 33: the roulette's throughput scaling, one reciprocal for the three quotients)
  *   op 40 = op 19 (same records, same outputs) through the fp16 centre / half-extent form of the nodes (NODE_FMT 11: pack_centre_half, slab_hc)
+ *   op 41 = op 40 with a scale per axis, as the builder uses it: in = ray o xyz, d xyz, box lo xyz, hi xyz, scene centre xyz, inv_scale xyz, tmax (19 floats)
  *   op 39 shared-plane slab test (NODE_FMT 10, pt_device.h SSpace): in float[n][20] = ray o xyz, d xyz, box lo xyz, hi xyz, root planes L xyz, H xyz,
  *         inv_scale, tmax; the box as child 0 and as child 1 of a node whose other child is the root box.  out uint[n][3] = accepted as child 0,
  *         accepted as child 1, root accepted | sibling (the root box) accepted << 1 | << 2 */

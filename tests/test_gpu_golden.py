@@ -292,6 +292,43 @@ def test_gpu_fp16_slab_is_conservative(ctx):
             assert accepted[~wide].mean() < 1e-3, accepted[~wide].mean()
             print("fp16 slab test, %s, scaled by %.4f: %.2f %% of the rays that miss the box inflated by 2 %% of the scene are accepted, %.1f %% of all rays"
                   % (form, 1.0 / inv_scale, 100 * accepted[~wide].mean(), 100 * accepted.mean()))
+    # op 41: {centre, half extent} with a scale PER AXIS, what the builder gives NODE_FMT 11 (every face of the scene box at |g| = 1023).  The same
+    # cases in a scene squeezed to 1 / 3 and 1 / 40 of its size on y and z: boxes, origins and targets squeezed about the centre, directions re-aimed
+    sq = np.array([1.0, 0.313881, 1.0 / 40.0], np.float32)        # (y: the lower face lands at g = -321.1 under x's scale, between two fp16 values)
+    f = lambda p: (centre + (p - centre) * sq).astype(np.float32)
+    lo0s, hi0s, os_ = f(lo0), f(hi0), f(o)
+    ds = (d * sq).astype(np.float32)
+    ds = (ds / np.maximum(np.linalg.norm(ds.astype(np.float64), axis=1, keepdims=True), 1e-30)).astype(np.float32)
+    ds[np.abs(ds).max(axis=1) == 0] = np.array([0.0, 1.0, 0.0], np.float32)
+    pads = np.maximum(np.float32(1e-5) * np.maximum(np.float32(1.0), np.maximum(np.abs(lo0s), np.abs(hi0s))), pad_abs).astype(np.float32)
+    los, his = (lo0s - pads).astype(np.float32), (hi0s + pads).astype(np.float32)
+    must = _exact_slab(os_, ds, lo0s, hi0s, 0.01, tmax)
+    assert must.mean() > 0.2, "the squeezed cases lost their hits"
+    wide = _exact_slab(os_, ds, los - np.float32(0.02) * H * sq, his + np.float32(0.02) * H * sq, 0.01, tmax)
+    inv3 = (np.abs(np.concatenate([los, his]) - centre).max(axis=0) / np.float32(1023.0)).astype(np.float32)
+    assert inv3[0] > 2.5 * inv3[1] > 25 * inv3[2] > 0
+    rec = np.concatenate([os_, ds, los, his, np.broadcast_to(centre, (n, 3)), np.broadcast_to(inv3, (n, 3)), tmax[:, None]], axis=1).astype(np.float32)
+    assert rec.shape == (n, 19)
+    out = np.zeros((n, 3), np.uint32)
+    run(ctx, 41, np.ascontiguousarray(rec), n, out)
+    accepted = out[:, 0] == 1
+    missed = must & ~accepted
+    assert not missed.any(), "centre / half extent, a scale per axis: box test rejected %d of %d rays that meet the unpadded box, first: %s" % (missed.sum(), must.sum(), rec[np.argmax(missed)])
+    assert accepted[~wide].mean() < 1e-3, accepted[~wide].mean()
+    # a flat box on a face of the scene box is as thin as its pad: a ray that leaves it at 45 degrees is outside before tmin = 0.01 ... with one
+    # scale for all axes (op 40) the face of a short axis lies between two fp16 values and the same ray is still inside
+    wall = np.zeros((3, 19), np.float32)
+    face_y = np.float32(centre[1] - inv3[1] * 1023)                    # the scene box's lower y face
+    mid_u = np.float32((face_y + np.float32(1e-3) - centre[1]) / inv3[0])
+    assert np.float32(np.float16(mid_u)) > mid_u + np.float32(0.05)           # under one scale the wall's centre rounds into the scene: the box reaches 0.03 units in
+    for k, inv in enumerate((inv3, np.full(3, inv3[0], np.float32))):
+        wall[k, 0:3] = (centre[0], face_y + np.float32(3e-3), centre[2]); wall[k, 3:6] = (0.70710678, 0.70710678, 0.0)
+        wall[k, 6:9] = (centre[0] - 50, face_y, centre[2] - 1); wall[k, 9:12] = (centre[0] + 50, face_y + np.float32(2e-3), centre[2] + 1)
+        wall[k, 12:15] = centre; wall[k, 15:18] = inv; wall[k, 18] = 1e16
+    out = np.zeros((3, 3), np.uint32)
+    run(ctx, 41, np.ascontiguousarray(wall), 3, out)
+    assert out[0, 0] == 0 and out[1, 0] == 1, out[:2]
+    print("fp16 slab test, centre / half extent with a scale per axis: %.2f %% of the rays that miss the inflated box are accepted; a wall on a face of the scene box is left before tmin" % (100 * accepted[~wide].mean()))
 
 
 def test_gpu_shared_plane_slab_is_conservative(ctx):
