@@ -1210,6 +1210,42 @@ def test_lifetime_and_streams():
     assert free0 - free1 < 64 << 20, "device memory leaked: %d MiB" % ((free0 - free1) >> 20)
 
 
+def test_parallel_reinsertion_is_deterministic_and_prunes(gpu_state_factory, oracle, tmp_path):
+    """Build mode 2 above 16 384 triangles: the parallel reinsertion on the device (lbvh_build.hip section 13).  A 30 732-triangle scene built
+    twice gives the same tree — the same node visits and triangle tests, lane by lane, for a fixed ray stream (gains and node numbers decide
+    which moves win, not the order in which threads arrive) —, fewer of both than the PLOC tree it starts from, and the same hits as
+    brute force."""
+    import sys
+    sys.path.insert(0, pt.SCENES)
+    import make_scenes
+    path = str(tmp_path / "mid.obj")
+    make_scenes.stress_scene(path, n_spheres=24, subdiv=3, mtl_name="mid.mtl")
+    L = _native.hip()
+    closest = random_rays(150000, 51, lo=(20, 20, 20), hi=(530, 530, 540))
+    anyr = random_rays(50000, 52, lo=(20, 20, 20), hi=(530, 530, 540), tmin=0.01, tmax=300.0); anyr[:, 7] *= -1.0
+    rays = np.ascontiguousarray(np.concatenate([closest, anyr]).astype(np.float32))
+    n = rays.shape[0]
+    res = {}
+    for name, mode in (("ploc", 1), ("reinserted", 2), ("reinserted again", 2)):
+        state, obj = gpu_state_factory(path, width=64, height=64, build_mode=mode)
+        info = pt.getBvhInfo(state)
+        assert info.n_tris == 24 * 1280 + 12 > 16384 and info.max_depth < info.stack_entries
+        t = np.zeros(n, np.float32); prim = np.zeros(n, np.uint32); ms = C.c_float(); cnt = (C.c_uint64 * 5)()
+        assert L.pt_bench_traversal(state.context, rays.ctypes.data, n, 1, 0, t.ctypes.data, prim.ctypes.data, C.byref(ms), cnt) == 0
+        res[name] = (t, prim, int(cnt[1]), int(cnt[2]), int(info.max_depth))
+        if mode == 1:
+            sc = oracle.scene(obj.getVerticesFloat(), obj.getIndexBuffer(), obj.getMaterialIndices(), obj.getMaterials())
+            tb, pb = sc.trace_closest(np.ascontiguousarray(rays[:2000]), use_bvh=False)
+            sc.close()
+    a, b, p = res["reinserted"], res["reinserted again"], res["ploc"]
+    assert a[2:] == b[2:], "two builds of the same scene walk different trees: %s vs %s" % (a[2:], b[2:])
+    for r in (a, b):
+        assert np.array_equal(r[1], p[1]) and np.array_equal(r[0].view(np.uint32), p[0].view(np.uint32))
+    assert np.array_equal(p[1][:2000], pb) and np.array_equal(p[0][:2000].view(np.uint32), tb.view(np.uint32))
+    print("node visits / triangle tests summed over %d rays: PLOC %d / %d (height %d), after the parallel reinsertion %d / %d (height %d)" % (n, p[2], p[3], p[4], a[2], a[3], a[4]))
+    assert a[2] < 0.99 * p[2] and a[3] <= p[3]
+
+
 def test_ray_stream_kernel_bit_exact(full):
     """pt_bench_traversal (persistent ray-stream kernel, closest and any-hit rays mixed in one launch,
     more rays than resident lanes so the in-loop refill runs) against brute force."""
