@@ -1298,8 +1298,8 @@ static const VariantDesc kVariants[] = {
     ROW(256, 0, "pw K48 L8 fp32 nodes w4, two visits per loop trip (large scenes whose fp16 planes would be too coarse)", 0, 48, 8, 0, 256, 4, false, 0, 2, 1, false, 0, 0),
     ROW(256, 0, "TRIG fp32 nodes w4 with the cosine sampler's sin / cos / acos on v_sin_f32 / v_cos_f32 / sqrt (IEEE mode: everything else IEEE; other bits than its neighbours there)", 0, 48, 12, 0, 256, 4, false, 3, 1, 1, false, 0, 0),
     ROW(256, 8, "pw K44 L16 fp16 nodes (32 B), sign-rotated v_fma_mix planes, w4, three visits and two triangle tests per loop trip", 0, 44, 16, 8, 256, 4, false, 0, 3, 2, false, 0, 0),
-    ROW(256, 11, "pw K44 L16 fp16 centre / half-extent nodes, five visits per trip + scheduler stats (the default kernel's loop at four waves)", 0, 44, 16, 11, 256, 4, true, 0, 5, 2, false, 0, 0),
-    ROW(256, 11, "pw K40 L16 fp16 nodes (32 B) as centre / half extent per axis: two v_fma_mix_f32 and a full-rate subtract / add per axis and child, no rotates; FIVE waves per SIMD (96 registers), five visits and two triangle tests per loop trip", 0, 40, 16, 11, 256, 5, false, 0, 5, 2, false, 0, 0),
+    ROW(256, 11, "pw K44 L16 fp16 centre / half-extent nodes, six visits per trip + scheduler stats (the default kernel's loop at four waves)", 0, 44, 16, 11, 256, 4, true, 0, 6, 2, false, 0, 0),
+    ROW(256, 11, "pw K40 L16 fp16 nodes (32 B) as centre / half extent per axis: two v_fma_mix_f32 and a full-rate subtract / add per axis and child, no rotates; FIVE waves per SIMD (96 registers), six visits and two triangle tests per loop trip", 0, 40, 16, 11, 256, 5, false, 0, 6, 2, false, 0, 0),
     ROW(256, 11, "LIGHTS scene-driven area lights + MIS (light mode 1, opt-in: not the reference's estimator), fp16 centre / half-extent nodes w4", 0, 44, 16, 11, 256, 4, false, 0, 5, 2, true, 0, 0),
     ROW(256, 11, "pw K24 L16 fp16 centre / half-extent nodes, five waves per SIMD, for large scenes and deep trees: shade rounds at 24 parked lanes (rays are long there), a sliding window of 16 stack entries per lane in LDS, deeper ones moved to global memory four at a time", -16, 24, 16, 11, 256, 5, false, 0, 5, 2, false, -16, 0),
 #ifdef ACGPT_EXPERIMENTS

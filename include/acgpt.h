@@ -258,7 +258,7 @@ int pt_set_tuning(pt_ctx* ctx, int blocks_per_cu, int variant);
  * are timing experiments (some deliberately compute different bits) and are never selected by default; "FAST-MATH" and
  * "LIGHTS" (the kernel of pt_set_light_mode(1)) are opt-in and compute other bits than the reference's estimator. */
 const char* pt_variant_name(int variant);
-/* The variant's kernel in a math mode as a kernel trace prints it ("k_render_pw<40, 16, 11, 256, 5, false, 0, 5, 2, false, 0, 0, 1>":
+/* The variant's kernel in a math mode as a kernel trace prints it ("k_render_pw<40, 16, 11, 256, 5, false, 0, 6, 2, false, 0, 0, 1>":
  * the last argument is the math mode), and a hash of the kernel sources this library was built from: what bench.py checks a
  * committed profile against before quoting it. */
 const char* pt_variant_kernel(int variant, int math_mode);

@@ -127,5 +127,5 @@ def kernel_mix(lib, kernel_substr):
 
 if __name__ == "__main__":
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "acgpathtracing_amd", "libacgpt_hip.so")
-    kern = sys.argv[2] if len(sys.argv) > 2 else "k_render_pw<40, 16, 11, 256, 5, false, 0, 5, 2, false, 0, 0, 1>"
+    kern = sys.argv[2] if len(sys.argv) > 2 else "k_render_pw<40, 16, 11, 256, 5, false, 0, 6, 2, false, 0, 0, 1>"
     print(json.dumps(kernel_mix(lib, kern), indent=1))
