@@ -1154,10 +1154,10 @@ PT_API int pt_trace_any(pt_ctx* c, const float* rays, size_t n, uint8_t* hit_out
 PT_API int pt_bench_traversal(pt_ctx* c, const float* rays, size_t n, int repeats, int node_format, float* t_out, uint32_t* prim_out, float* ms_out,
                               uint64_t* counters_out)
 {
-    if (!c || !rays || !t_out || !prim_out || !ms_out || n == 0 || n > 0x7FFFFFFFull || repeats < 1 || node_format < 0 || node_format > 3)
+    if (!c || !rays || !t_out || !prim_out || !ms_out || n == 0 || n > 0x7FFFFFFFull || repeats < 1 || node_format < 0 || node_format > 4)
         return fail(c, "pt_bench_traversal: bad argument");
     CK(c, hipSetDevice(c->device));
-    if (int rc = ensure_node_format(c, node_format == 1 ? 3 : node_format == 3 ? 9 : 0)) return rc;       // stream formats 0 / 2: fp32 nodes, 3: fp16, 1: four-wide
+    if (int rc = ensure_node_format(c, node_format == 1 ? 3 : node_format == 3 ? 9 : node_format == 4 ? 11 : 0)) return rc;       // stream formats 0 / 2: fp32 nodes, 3: fp16 {lo, hi}, 4: fp16 {centre, half extent}, 1: four-wide
     const uint32_t entries = node_format == 1 ? (c->bvh.wide_depth + 1u) : c->stack_entries;
     float* d_rays = nullptr; float* d_t = nullptr; uint32_t* d_p = nullptr; uint32_t* d_head = nullptr;
     int bpc = 0;

@@ -1042,6 +1042,7 @@ k_trace_stream(const DeviceScene sc, uint32_t stack_entries, const float4* __res
                     any_ray = b.w < 0.0f; rtmax = fabsf(b.w);
                     if (FMT == 2) setup_ray<0>(ro, rd, sc.grid, sc.hspace, rinv, roi);
                     else if (FMT == 3) setup_ray<7>(ro, rd, sc.grid, sc.hspace, rinv, roi);
+                    else if (FMT == 4) setup_ray<11>(ro, rd, sc.grid, sc.hspace, rinv, roi);
                     else rinv = mk(fast_rcp(rd.x), fast_rcp(rd.y), fast_rcp(rd.z));
                     best_t = rtmax; best_slot = -1; best_prim = 0xFFFFFFFFu; any_hit = false;
                     node = sc.n_tris ? 0 : kSentinel; sp = 0;
@@ -1058,7 +1059,15 @@ k_trace_stream(const DeviceScene sc, uint32_t stack_entries, const float4* __res
         { const unsigned long long vm = vote(node >= 0 && node != kSentinel); n_iter++; n_visit += (unsigned long long)popc(vm); n_vround += vm ? 1u : 0u; }
         if (node >= 0 && node != kSentinel) {
             float x0, x1, y0, y1, z0, z1, u0, u1, v0, v1, w0, w1;
+            float n0, f0, n1, f1;
             int2 ch;
+            if (FMT == 4) {        // the default render kernels' nodes and box test (NODE_FMT 11): fp16 {centre, half extent}, a scale per axis, child references as byte offsets
+                const uint4* hp = (const uint4*)((const char*)sc.hcnodes + (size_t)(uint32_t)node);
+                const uint4 qa = hp[0], qb = hp[1];
+                ch = make_int2((int)qa.w, (int)qb.w);
+                slab_hc(qa.x, qa.y, qa.z, rinv, roi, rtmin, n0, f0);
+                slab_hc(qb.x, qb.y, qb.z, rinv, roi, rtmin, n1, f1);
+            } else {
             if (FMT == 3) {        // fp16 nodes, two loads, v_fma_mix_f32 planes: the render kernel's NODE_FMT 7
                 const uint4* hp = (const uint4*)(sc.hnodes + node);
                 const uint4 qa = hp[0], qb = hp[1];
@@ -1089,10 +1098,11 @@ k_trace_stream(const DeviceScene sc, uint32_t stack_entries, const float4* __res
                 w0 = (c.x - ro.z) * rinv.z; w1 = (c.w - ro.z) * rinv.z;
             }
             }
-            float n0 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), rtmin));
-            float f0 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1)) * kFarWiden;
-            float n1 = fmaxf(fmaxf(fminf(u0, u1), fminf(v0, v1)), fmaxf(fminf(w0, w1), rtmin));
-            float f1 = fminf(fminf(fmaxf(u0, u1), fmaxf(v0, v1)), fmaxf(w0, w1)) * kFarWiden;
+            n0 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), rtmin));
+            f0 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1)) * kFarWiden;
+            n1 = fmaxf(fmaxf(fminf(u0, u1), fminf(v0, v1)), fmaxf(fminf(w0, w1), rtmin));
+            f1 = fminf(fminf(fmaxf(u0, u1), fmaxf(v0, v1)), fmaxf(w0, w1)) * kFarWiden;
+            }
             f0 = fminf(f0, best_t * kTieWiden);
             f1 = fminf(f1, best_t * kTieWiden);
             const bool h0 = n0 <= f0, h1 = n1 <= f1;
@@ -1245,7 +1255,7 @@ k_trace_stream_w4(const DeviceScene sc, uint32_t stack_entries, const float4* __
 }
 
 // fmt 0: two-child fp32 tree (stack_entries dwords per lane); fmt 1: four-wide tree (stack_entries 8-byte groups);
-// fmt 2: two-child fp32 tree, fma slab test; fmt 3: two-child fp16 nodes
+// fmt 2: two-child fp32 tree, fma slab test; fmt 3: two-child fp16 {lo, hi} nodes; fmt 4: fp16 {centre, half extent} nodes, what the default render kernels walk
 typedef void (*StreamKernel)(const DeviceScene, uint32_t, const float4*, uint32_t, uint32_t*, float*, uint32_t*, unsigned long long*);
 static StreamKernel stream_kernel(int fmt)
 {
@@ -1253,6 +1263,7 @@ static StreamKernel stream_kernel(int fmt)
         case 1: return k_trace_stream_w4<8, 8>;
         case 2: return k_trace_stream<8, 8, 2>;
         case 3: return k_trace_stream<8, 8, 3>;
+        case 4: return k_trace_stream<8, 8, 4>;
         default: return k_trace_stream<8, 8, 0>;
     }
 }

@@ -17,7 +17,8 @@ extern "C" {
 /* Diagnostic: pure-traversal throughput.  Streams n HOST rays (same 8-float records; tmax < 0 marks an
  * any-hit ray of length |tmax|) through a persistent kernel that contains nothing but the BVH loop, `repeats`
  * times, and reports the fastest kernel time.  node_format 0: two-child fp32 tree; 1: four-wide 8-bit tree;
- * 2: two-child tree with the slab test as one fma per plane (the render kernel's form).
+ * 2: two-child tree with the slab test as one fma per plane (the fp32 render kernels' form); 3: fp16 {lo, hi} nodes (rounds 2-3's default);
+ * 4: fp16 {centre, half extent} nodes with a scale per axis — the array and the box test the default render kernels use.
  * Results: closest rays as pt_trace_closest; any-hit rays give t_out = prim_out = 1 when occluded, 0
  * otherwise.  counters_out (may be NULL): 5 values of the last repeat — loop iterations summed over waves,
  * node visits summed over lanes, triangle tests summed over lanes, iterations with a node visit, iterations

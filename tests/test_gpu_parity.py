@@ -773,6 +773,11 @@ def test_large_scene_properties(gpu_state_factory, oracle, tmp_path):
     assert np.array_equal(hit != 0, prim != 0xFFFFFFFF)                       # (c) any-hit <=> a closest hit exists
     tb, pb = sc.trace_closest(rays[:150], use_bvh=False)                       # (a) brute force sample
     assert np.array_equal(prim[:150], pb) and np.array_equal(t[:150].view(np.uint32), tb.view(np.uint32))
+    # the node array and box test the render kernel itself walks on this scene — fp16 {centre, half extent}, a scale per axis, the reinserted
+    # tree in depth-first order — through the ray-stream kernel (stream format 4): the same hits
+    ts = np.zeros(n, np.float32); prims = np.zeros(n, np.uint32); ms = C.c_float()
+    assert L.pt_bench_traversal(state.context, rays.ctypes.data, n, 1, 4, ts.ctypes.data, prims.ctypes.data, C.byref(ms), None) == 0
+    assert np.array_equal(prims, p_ref) and np.array_equal(ts.view(np.uint32), t_ref.view(np.uint32))
     # the other builder, same answers
     assert L.pt_set_build_mode(state.context, 0) == 0
     pt.buildTheAccelarationStructure(state, obj)
@@ -1233,6 +1238,9 @@ def test_parallel_reinsertion_is_deterministic_and_prunes(gpu_state_factory, ora
         t = np.zeros(n, np.float32); prim = np.zeros(n, np.uint32); ms = C.c_float(); cnt = (C.c_uint64 * 5)()
         assert L.pt_bench_traversal(state.context, rays.ctypes.data, n, 1, 0, t.ctypes.data, prim.ctypes.data, C.byref(ms), cnt) == 0
         res[name] = (t, prim, int(cnt[1]), int(cnt[2]), int(info.max_depth))
+        t4 = np.zeros(n, np.float32); prim4 = np.zeros(n, np.uint32)         # and through the fp16 nodes the render kernel walks: the same answers
+        assert L.pt_bench_traversal(state.context, rays.ctypes.data, n, 1, 4, t4.ctypes.data, prim4.ctypes.data, C.byref(ms), None) == 0
+        assert np.array_equal(prim4, prim) and np.array_equal(t4.view(np.uint32), t.view(np.uint32)), name
         if mode == 1:
             sc = oracle.scene(obj.getVerticesFloat(), obj.getIndexBuffer(), obj.getMaterialIndices(), obj.getMaterials())
             tb, pb = sc.trace_closest(np.ascontiguousarray(rays[:2000]), use_bvh=False)
@@ -1263,7 +1271,7 @@ def test_ray_stream_kernel_bit_exact(full):
     t_ref, prim_ref = sc.trace_closest(np.ascontiguousarray(rays[is_c]), use_bvh=False)
     ar = np.ascontiguousarray(rays[~is_c]); ar[:, 7] *= -1.0
     any_ref = sc.trace_any(ar, use_bvh=False) != 0
-    for fmt in (0, 1, 2, 3):                                 # two-child fp32 tree, four-wide 8-bit tree, two-child with the fma slab test, fp16 nodes
+    for fmt in (0, 1, 2, 3, 4):                              # two-child fp32 tree, four-wide 8-bit tree, two-child with the fma slab test, fp16 {lo, hi} nodes, fp16 {centre, half extent} nodes (what the default render kernels walk)
         t = np.zeros(n, np.float32); prim = np.zeros(n, np.uint32); ms = C.c_float()
         assert L.pt_bench_traversal(state.context, rays.ctypes.data, n, 2, fmt, t.ctypes.data, prim.ctypes.data, C.byref(ms), None) == 0
         assert np.array_equal(prim[is_c], prim_ref) and np.array_equal(t[is_c].view(np.uint32), t_ref.view(np.uint32)), fmt

@@ -26,7 +26,7 @@ def main():
     L = _native.hip()
     orc = oracle_lib.load()
     bad = 0
-    for mode in (1, 0):
+    for mode in (2, 1, 0):          # the default (PLOC + insertion-based optimisation), PLOC, Karras
         state, obj = pt.setup(os.path.join(pt.SCENES, a.scene), width=64, height=64, build_mode=mode)
         sc = orc.scene(obj.getVerticesFloat(), obj.getIndexBuffer(), obj.getMaterialIndices(), obj.getMaterials())
         v, idx = scene_arrays(obj)
@@ -41,7 +41,7 @@ def main():
             assert L.pt_trace_closest(state.context, rays.ctypes.data, n, t.ctypes.data, p.ctypes.data) == 0
             assert L.pt_trace_any(state.context, rays.ctypes.data, n, h.ctypes.data) == 0
             res = {"query": (t.copy(), p.copy())}
-            for fmt in (0, 1, 2):
+            for fmt in (0, 1, 2, 3, 4):
                 assert L.pt_bench_traversal(state.context, rays.ctypes.data, n, 1, fmt, t.ctypes.data, p.ctypes.data, C.byref(ms), None) == 0
                 res["stream fmt %d" % fmt] = (t.copy(), p.copy())
             t_b, p_b = sc.trace_closest(rays, use_bvh=True)
@@ -56,7 +56,7 @@ def main():
             if m.any():
                 bad += int(m.sum()); print("MISMATCH any-hit mode %d seed %d: %d rays" % (mode, s, int(m.sum())))
             ar = rays.copy(); ar[:, 7] *= -1.0
-            for fmt in (0, 1, 2):
+            for fmt in (0, 1, 2, 3, 4):
                 assert L.pt_bench_traversal(state.context, ar.ctypes.data, n, 1, fmt, t.ctypes.data, p.ctypes.data, C.byref(ms), None) == 0
                 m = (p != 0) != a_ref
                 if m.any():
