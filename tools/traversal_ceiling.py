@@ -95,7 +95,7 @@ def main():
     print("two-child tree: %d nodes, depth %d, build %.2f ms; four-wide tree: %d nodes, depth %d, collapse %.2f ms (host)"
           % (info.n_nodes, info.max_depth, info.build_ms, info.wide_nodes, info.wide_depth, info.wide_ms))
     for fmt, name in ((0, "two-child fp32 nodes (64 B)"), (1, "four-wide 8-bit nodes (48 B)"), (2, "two-child, fma slab test"),
-                      (3, "two-child fp16 nodes (32 B)")):
+                      (3, "two-child fp16 {lo, hi} nodes (32 B)"), (4, "fp16 {centre, half}, scale per axis")):
         t_out = np.zeros(n, np.float32); p_out = np.zeros(n, np.uint32); ms = C.c_float()
         cnt = np.zeros(5, np.uint64)
         assert L.pt_bench_traversal(state.context, R.ctypes.data, n, a.repeats, fmt, t_out.ctypes.data, p_out.ctypes.data, C.byref(ms), cnt.ctypes.data) == 0, L.pt_last_error(state.context)
