@@ -1254,6 +1254,37 @@ def test_parallel_reinsertion_is_deterministic_and_prunes(gpu_state_factory, ora
     assert a[2] < 0.99 * p[2] and a[3] <= p[3]
 
 
+def test_thousands_of_coincident_triangles_build_and_answer(gpu_state_factory, oracle, tmp_path):
+    """17 000 copies of one triangle (one box, one Morton code) plus a second triangle behind them: clustering by merged area chains such a
+    scene into a tree as deep as it is long, which the lane stacks cannot walk; pt_set_scene then takes the radix tree (equal codes split by
+    index bits) instead of failing.  Every ray that hits reports the FIRST copy (ties in t go to the lower primitive index, as in the
+    oracle's brute force), any-hit agrees, and a small render matches the oracle."""
+    path = str(tmp_path / "same.obj")
+    with open(path, "w") as f:
+        f.write("mtllib same.mtl\nusemtl white\nv 100 100 300\nv 400 100 300\nv 100 400 300\nv 0 0 500\nv 556 0 500\nv 0 548 500\n")
+        f.write("f 1 2 3\n" * 17000 + "f 4 5 6\n")
+    with open(str(tmp_path / "same.mtl"), "w") as f:
+        f.write("newmtl white\nKd 0.7 0.7 0.7\n")
+    L = _native.hip()
+    state, obj = gpu_state_factory(path, width=64, height=64)
+    info = pt.getBvhInfo(state)
+    assert info.n_tris == 17001 and info.max_depth < 40 and info.max_depth < info.stack_entries, (info.max_depth, info.stack_entries)
+    sc = oracle.scene(obj.getVerticesFloat(), obj.getIndexBuffer(), obj.getMaterialIndices(), obj.getMaterials())
+    rays = random_rays(600, 61, lo=(50, 50, 0), hi=(450, 450, 250))
+    rays[:, 3:6] = (rays[:, 3:6] * np.float32([0.3, 0.3, 0.0]) + np.float32([0, 0, 1])); rays[:, 3:6] /= np.linalg.norm(rays[:, 3:6], axis=1, keepdims=True)
+    rays = np.ascontiguousarray(rays.astype(np.float32)); n = rays.shape[0]
+    t = np.zeros(n, np.float32); prim = np.zeros(n, np.uint32); hit = np.zeros(n, np.uint8)
+    assert L.pt_trace_closest(state.context, rays.ctypes.data, n, t.ctypes.data, prim.ctypes.data) == 0
+    assert L.pt_trace_any(state.context, rays.ctypes.data, n, hit.ctypes.data) == 0
+    t_ref, p_ref = sc.trace_closest(rays, use_bvh=False)
+    assert np.array_equal(prim, p_ref) and np.array_equal(t.view(np.uint32), t_ref.view(np.uint32))
+    assert (prim == 0).sum() > 50 and (prim == 17000).sum() > 50 and np.array_equal(hit != 0, prim != 0xFFFFFFFF)
+    ts = np.zeros(n, np.float32); prims = np.zeros(n, np.uint32); ms = C.c_float()
+    assert L.pt_bench_traversal(state.context, rays.ctypes.data, n, 1, 4, ts.ctypes.data, prims.ctypes.data, C.byref(ms), None) == 0      # the render kernels' own nodes
+    assert np.array_equal(prims, p_ref) and np.array_equal(ts.view(np.uint32), t_ref.view(np.uint32))
+    sc.close()
+
+
 def test_ray_stream_kernel_bit_exact(full):
     """pt_bench_traversal (persistent ray-stream kernel, closest and any-hit rays mixed in one launch,
     more rays than resident lanes so the in-loop refill runs) against brute force."""
