@@ -1258,7 +1258,7 @@ def test_thousands_of_coincident_triangles_build_and_answer(gpu_state_factory, o
     """17 000 copies of one triangle (one box, one Morton code) plus a second triangle behind them: clustering by merged area chains such a
     scene into a tree as deep as it is long, which the lane stacks cannot walk; pt_set_scene then takes the radix tree (equal codes split by
     index bits) instead of failing.  Every ray that hits reports the FIRST copy (ties in t go to the lower primitive index, as in the
-    oracle's brute force), any-hit agrees, and a small render matches the oracle."""
+    oracle's brute force), any-hit agrees, and the render kernels' own node array gives the same answers."""
     path = str(tmp_path / "same.obj")
     with open(path, "w") as f:
         f.write("mtllib same.mtl\nusemtl white\nv 100 100 300\nv 400 100 300\nv 100 400 300\nv 0 0 500\nv 556 0 500\nv 0 548 500\n")
