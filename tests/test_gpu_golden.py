@@ -315,6 +315,29 @@ def test_gpu_fp16_slab_is_conservative(ctx):
     missed = must & ~accepted
     assert not missed.any(), "centre / half extent, a scale per axis: box test rejected %d of %d rays that meet the unpadded box, first: %s" % (missed.sum(), must.sum(), rec[np.argmax(missed)])
     assert accepted[~wide].mean() < 1e-3, accepted[~wide].mean()
+    # and a FLAT scene: everything in the plane z = centre.z (the z axis holds nothing but the boxes' pad: its scale is 2^19 / 1023 times the x axis'),
+    # rays through it from both sides, a thousandth of them in the plane
+    sqf = np.array([1.0, 0.5, 0.0], np.float32)
+    ff = lambda p: (centre + (p - centre) * sqf).astype(np.float32)
+    lo0f, hi0f = ff(lo0), ff(hi0)
+    of = (centre + (o - centre) * np.array([1.0, 0.5, 0.05], np.float32)).astype(np.float32)
+    tgt = ff(target)
+    df = (tgt - of).astype(np.float32)
+    inplane = rng.random(n) < 1e-3
+    df[inplane, 2] = 0.0; of[inplane, 2] = centre[2]
+    df = (df / np.maximum(np.linalg.norm(df.astype(np.float64), axis=1, keepdims=True), 1e-30)).astype(np.float32)
+    df[np.abs(df).max(axis=1) == 0] = np.array([0.0, 1.0, 0.0], np.float32)
+    padf = np.maximum(np.float32(1e-5) * np.maximum(np.float32(1.0), np.maximum(np.abs(lo0f), np.abs(hi0f))), pad_abs).astype(np.float32)
+    lof, hif = (lo0f - padf).astype(np.float32), (hi0f + padf).astype(np.float32)
+    mustf = _exact_slab(of, df, lo0f, hi0f, 0.01, tmax)
+    assert mustf.mean() > 0.1, "the flat cases lost their hits"
+    inv3f = (np.abs(np.concatenate([lof, hif]) - centre).max(axis=0) / np.float32(1023.0)).astype(np.float32)
+    assert inv3f[2] < 1e-4 * inv3f[0]
+    recf = np.concatenate([of, df, lof, hif, np.broadcast_to(centre, (n, 3)), np.broadcast_to(inv3f, (n, 3)), tmax[:, None]], axis=1).astype(np.float32)
+    outf = np.zeros((n, 3), np.uint32)
+    run(ctx, 41, np.ascontiguousarray(recf), n, outf)
+    missedf = mustf & ~(outf[:, 0] == 1)
+    assert not missedf.any(), "flat scene, a scale per axis: box test rejected %d of %d rays that meet the unpadded box, first: %s" % (missedf.sum(), mustf.sum(), recf[np.argmax(missedf)])
     # a flat box on a face of the scene box is as thin as its pad: a ray that leaves it at 45 degrees is outside before tmin = 0.01 ... with one
     # scale for all axes (op 40) the face of a short axis lies between two fp16 values and the same ray is still inside
     wall = np.zeros((3, 19), np.float32)

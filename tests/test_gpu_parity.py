@@ -1285,6 +1285,49 @@ def test_thousands_of_coincident_triangles_build_and_answer(gpu_state_factory, o
     sc.close()
 
 
+def test_flat_scene_hits(gpu_state_factory, oracle, tmp_path):
+    """A scene with no extent on one axis — 45 000 triangles of a grid in the plane y = 50 —: the fp16 nodes' y axis holds nothing but the
+    boxes' pad (its scale is 2^19 / 1023 times the others'), the tree is optimised on the device, and rays from both sides, grazing ones
+    included, hit what brute force says, through the query kernels and through the render kernels' own node array."""
+    k = 150
+    path = str(tmp_path / "flat.obj")
+    with open(path, "w") as f:
+        f.write("mtllib flat.mtl\nusemtl white\n")
+        for j in range(k + 1):
+            for i in range(k + 1):
+                f.write("v %r 50 %r\n" % (i * 500.0 / k, j * 500.0 / k))
+        for j in range(k):
+            for i in range(k):
+                a = j * (k + 1) + i + 1
+                f.write("f %d %d %d\nf %d %d %d\n" % (a, a + 1, a + k + 2, a, a + k + 2, a + k + 1))
+    with open(str(tmp_path / "flat.mtl"), "w") as f:
+        f.write("newmtl white\nKd 0.7 0.7 0.7\n")
+    L = _native.hip()
+    state, obj = gpu_state_factory(path, width=64, height=64)
+    info = pt.getBvhInfo(state)
+    assert info.n_tris == 2 * k * k and info.max_depth < info.stack_entries
+    sc = oracle.scene(obj.getVerticesFloat(), obj.getIndexBuffer(), obj.getMaterialIndices(), obj.getMaterials())
+    rng = np.random.default_rng(71)
+    n = 400
+    rays = np.zeros((n, 8), np.float32)
+    rays[:, 0] = rng.uniform(-50, 550, n); rays[:, 2] = rng.uniform(-50, 550, n)
+    rays[:, 1] = 50 + rng.choice([-1.0, 1.0], n) * np.exp(rng.uniform(np.log(1e-2), np.log(300.0), n))        # a hair above / below the plane up to far away
+    tgt = np.stack([rng.uniform(0, 500, n), np.full(n, 50.0), rng.uniform(0, 500, n)], axis=1)
+    d = tgt - rays[:, 0:3]
+    rays[:, 3:6] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 6] = 0.01; rays[:, 7] = 1e16
+    rays = np.ascontiguousarray(rays)
+    t = np.zeros(n, np.float32); prim = np.zeros(n, np.uint32); ms = C.c_float()
+    assert L.pt_trace_closest(state.context, rays.ctypes.data, n, t.ctypes.data, prim.ctypes.data) == 0
+    t_ref, p_ref = sc.trace_closest(rays, use_bvh=False)
+    assert np.array_equal(prim, p_ref) and np.array_equal(t.view(np.uint32), t_ref.view(np.uint32))
+    assert (prim != 0xFFFFFFFF).mean() > 0.9
+    ts = np.zeros(n, np.float32); prims = np.zeros(n, np.uint32)
+    assert L.pt_bench_traversal(state.context, rays.ctypes.data, n, 1, 4, ts.ctypes.data, prims.ctypes.data, C.byref(ms), None) == 0
+    assert np.array_equal(prims, p_ref) and np.array_equal(ts.view(np.uint32), t_ref.view(np.uint32))
+    sc.close()
+
+
 def test_ray_stream_kernel_bit_exact(full):
     """pt_bench_traversal (persistent ray-stream kernel, closest and any-hit rays mixed in one launch,
     more rays than resident lanes so the in-loop refill runs) against brute force."""
