@@ -401,9 +401,10 @@ static int set_scene_one(pt_ctx* c, const float* verts_xyzw, size_t n_verts, con
     std::string err;
     if (!ptd::build_lbvh(verts_xyzw, n_verts, idx, n_tris, mat_ids, c->build_mode, c->stream, c->bvh, err)) return fail(c, "pt_set_scene: " + err);
     if (c->build_mode != 0 && c->bvh.max_depth + 1u > 128u) {
-        // Clustering by merged area has nothing to go by when thousands of triangles coincide (one box, one Morton code): it chains them, and
-        // the tree outgrows the 128-entry lane stacks (size_stack below).  The radix tree splits equal codes by their index bits and stays
-        // logarithmic: such a scene gets it instead of an error (tools/degenerate_scenes.py same 20000: depth 20 000 -> 27).
+        // Clustering by merged area has nothing to go by when thousands of triangles coincide (one box, one Morton code).  The builder pairs
+        // ties by a hash once it sees the merges stall (lbvh_build.hip k_ploc_nn: 20 000 copies of one triangle, 96 levels instead of 20 000);
+        // should a tree still outgrow the 128-entry lane stacks (size_stack below), the radix tree — equal codes split by their index bits,
+        // always logarithmic — is taken instead of an error.
         free_scene(c);
         if (!ptd::build_lbvh(verts_xyzw, n_verts, idx, n_tris, mat_ids, 0, c->stream, c->bvh, err)) return fail(c, "pt_set_scene: " + err);
     }

@@ -371,7 +371,7 @@ __global__ void k_single_node(const float4* __restrict__ tri_lo, const float4* _
 // each side in the current order for the partner with the smallest merged surface area, mutual
 // nearest neighbours merge, the sequence is compacted, repeat until one cluster is left.  Quality
 // is that of a full SAH sweep (-29 % inner-node visits per ray on the Cornell scene against the
-// Karras tree, profiles/r01_bvh_quality.txt).  Deterministic: ties go to the lower index and node
+// Karras tree, profiles/r01_bvh_quality.txt).  Deterministic: ties go to the lower index (to hashed pairs once ties hold the merges up, k_ploc_nn) and node
 // numbers come from prefix sums, not atomics.  Node 0 is the root (numbers are handed out downwards).
 constexpr int kPlocRadius = 8;
 constexpr uint32_t kReinsertIterations = 12;     // parallel reinsertion (13): at most this many find / lock / apply / refit rounds
@@ -406,7 +406,7 @@ __device__ __forceinline__ float merged_area(const float4& al, const float4& ah,
 // The round loop runs on the device's own counters: PlocState holds the current cluster count and the next free node number,
 // every kernel of a round reads them, the last one advances them.  The host enqueues rounds in batches and looks at the
 // count once per batch, instead of synchronising (and copying four words back) after every round.
-struct PlocState { uint32_t m, next_top, kept, made, rounds, pad0, pad1, pad2; };
+struct PlocState { uint32_t m, next_top, kept, made, rounds, hashed_ties, pad1, pad2; };
 
 __global__ void k_ploc_nn(const Cluster* __restrict__ c, const PlocState* __restrict__ st, uint32_t* __restrict__ nn)
 {
@@ -416,11 +416,19 @@ __global__ void k_ploc_nn(const Cluster* __restrict__ c, const PlocState* __rest
     const float4 l = c[i].lo, h = c[i].hi;
     const uint32_t a = i > (uint32_t)kPlocRadius ? i - kPlocRadius : 0u;
     const uint32_t b = min(m, i + kPlocRadius + 1u);
-    float best = INFINITY; uint32_t bj = i;
+    // Ties in the merged area go to the lower index.  That rule makes every cluster of a regular sequence — a strip of identical quads, a fence,
+    // a staircase: each has two equally good neighbours — point the same way, so that one pair per round is mutual and the build takes
+    // (almost) as many rounds as there are triangles: 100 000 triangles of a strip 1.77 s, tools/degenerate_scenes.py.  When the host sees
+    // a batch of rounds that hardly shrank the sequence it sets st->hashed_ties: ties then go to the pair with the smaller hash of its lower
+    // position — a key both partners compute alike —, a third of the positions are local minima of it and merge in the same round (3 ms).
+    // Ordinary scenes never switch: their trees are those of rounds 1-3 (the hash as the general rule cost the 1.31 M-triangle scene 2.5 %).
+    const bool hashed = st->hashed_ties != 0u;
+    float best = INFINITY; uint32_t bj = i, bkey = 0xFFFFFFFFu;
     for (uint32_t j = a; j < b; j++) {
         if (j == i) continue;
         const float ar = merged_area(l, h, c[j].lo, c[j].hi);
-        if (ar < best) { best = ar; bj = j; }      // ascending j: ties keep the lower index
+        const uint32_t key = hashed ? (j < i ? j : i) * 0x9E3779B1u : 0u;
+        if (ar < best || (ar == best && key < bkey)) { best = ar; bj = j; bkey = key; }      // ascending j: without the hash, ties keep the lower index
     }
     nn[i] = bj;
 }
@@ -1250,6 +1258,11 @@ static bool build_impl(const float* h_verts_xyzw, size_t n_verts, const uint32_t
             HIPCK(hipMemcpyAsync(&h_st, d_st, sizeof(h_st), hipMemcpyDeviceToHost, stream));
             HIPCK(hipStreamSynchronize(stream));
             if (h_st.m >= m_ub && h_st.m > 1u) { err = "PLOC made no progress"; return false; }
+            if (h_st.hashed_ties == 0u && m_ub > 1024u && h_st.m > m_ub - m_ub / 4u) {      // eight rounds took less than a quarter off (ordinary scenes: a third per ROUND): ties are holding the merges up (k_ploc_nn)
+                const uint32_t one = 1u;
+                HIPCK(hipMemcpyAsync(&d_st->hashed_ties, &one, 4, hipMemcpyHostToDevice, stream));
+                if (getenv("ACGPT_DEBUG_BUILD")) fprintf(stderr, "[acgpt build] PLOC: %u -> %u clusters in %d rounds, ties go to hashed pairs from here\n", m_ub, h_st.m, kBatch);
+            }
             m_ub = h_st.m;
         }
         out.build_iterations = h_st.rounds;

@@ -1255,9 +1255,10 @@ def test_parallel_reinsertion_is_deterministic_and_prunes(gpu_state_factory, ora
 
 
 def test_thousands_of_coincident_triangles_build_and_answer(gpu_state_factory, oracle, tmp_path):
-    """17 000 copies of one triangle (one box, one Morton code) plus a second triangle behind them: clustering by merged area chains such a
-    scene into a tree as deep as it is long, which the lane stacks cannot walk; pt_set_scene then takes the radix tree (equal codes split by
-    index bits) instead of failing.  Every ray that hits reports the FIRST copy (ties in t go to the lower primitive index, as in the
+    """17 000 copies of one triangle (one box, one Morton code) plus a second triangle behind them: clustering by merged area, ties to the
+    lower index, chains such a scene into a tree as deep as it is long, which the lane stacks cannot walk.  The builder notices that the merges
+    stall and pairs ties by a hash (k_ploc_nn), and pt_set_scene would take the radix tree (equal codes split by index bits) rather than fail
+    on a tree deeper than 128 levels.  Every ray that hits reports the FIRST copy (ties in t go to the lower primitive index, as in the
     oracle's brute force), any-hit agrees, and the render kernels' own node array gives the same answers."""
     path = str(tmp_path / "same.obj")
     with open(path, "w") as f:
@@ -1268,7 +1269,7 @@ def test_thousands_of_coincident_triangles_build_and_answer(gpu_state_factory, o
     L = _native.hip()
     state, obj = gpu_state_factory(path, width=64, height=64)
     info = pt.getBvhInfo(state)
-    assert info.n_tris == 17001 and info.max_depth < 40 and info.max_depth < info.stack_entries, (info.max_depth, info.stack_entries)
+    assert info.n_tris == 17001 and info.max_depth < info.stack_entries <= 128, (info.max_depth, info.stack_entries)
     sc = oracle.scene(obj.getVerticesFloat(), obj.getIndexBuffer(), obj.getMaterialIndices(), obj.getMaterials())
     rays = random_rays(600, 61, lo=(50, 50, 0), hi=(450, 450, 250))
     rays[:, 3:6] = (rays[:, 3:6] * np.float32([0.3, 0.3, 0.0]) + np.float32([0, 0, 1])); rays[:, 3:6] /= np.linalg.norm(rays[:, 3:6], axis=1, keepdims=True)

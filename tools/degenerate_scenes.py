@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Large degenerate scenes through the hierarchy builders (PLOC as built, and the default with its tree optimisation): n copies of one triangle,
 a flat grid of triangles in one plane, n long slivers a hair apart.  Build time and tree depth; a build that does not come back is the failure
-looked for.  usage: python tools/degenerate_scenes.py {same|plane|sliver} <n>"""
+looked for.  usage: python tools/degenerate_scenes.py {same|plane|strip|sliver} <n>"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
@@ -23,6 +23,11 @@ with open(path, "w") as f:
             for i in range(k):
                 a = j * (k + 1) + i + 1
                 f.write("f %d %d %d\nf %d %d %d\n" % (a, a + 1, a + k + 2, a, a + k + 2, a + k + 1)); c += 2
+    elif kind == "strip":          # a long strip of identical unit quads at integer spacing (a fence, a staircase, a tessellated band): every merged area ties with its mirror image
+        for i in range(n // 2 + 1): f.write("v %d 0 0\nv %d 1 0\n" % (i, i))
+        for i in range(n // 2):
+            a = 2 * i + 1
+            f.write("f %d %d %d\nf %d %d %d\n" % (a, a + 2, a + 3, a, a + 3, a + 1))
     elif kind == "sliver":
         for i in range(n): f.write("v %g 0 0\nv %g 500 0.001\nv %g 0 500\n" % (i * 1e-3, i * 1e-3, i * 1e-3))
         for i in range(n): f.write("f %d %d %d\n" % (3 * i + 1, 3 * i + 2, 3 * i + 3))
