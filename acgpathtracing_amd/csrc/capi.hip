@@ -367,6 +367,7 @@ static int ensure_node_format(pt_ctx* c, int fmt)
         case 3: return ensure_wide(c);
         case 11: ok = ptd::ensure_hcnodes(c->bvh, c->stream, err); break;
 #ifdef ACGPT_EXPERIMENTS
+        case 13: case 14: ok = ptd::ensure_hcnodes(c->bvh, c->stream, err); break;
         case 10: ok = ptd::ensure_srecs(c->bvh, false, c->stream, err); break;       // 15-bit child references: scenes up to ~8 000 triangles
         case 12: ok = ptd::ensure_srecs(c->bvh, true, c->stream, err); break;
 #endif

@@ -175,7 +175,7 @@ __device__ __forceinline__ void setup_ray(const f3& ro, const f3& rd, const QGri
         gro = mk(-(ro.x * rinv.x), -(ro.y * rinv.y), -(ro.z * rinv.z));
     } else if (NODE_FMT == 9) {                      // the same with the rotate amounts in the multipliers (pt_device.h)
         setup_ray_h9(ro, rd, HS, rinv, gro);
-    } else if (NODE_FMT == 11) {                     // fp16 centre / half-extent nodes: the plain multiplier and addend
+    } else if (NODE_FMT == 11 || NODE_FMT == 13 || NODE_FMT == 14) {   // fp16 centre / half-extent nodes: the plain multiplier and addend
         setup_ray_hc(ro, rd, HS, rinv, gro);
     } else if (NODE_FMT == 7 || NODE_FMT == 8) {     // t = g * (1/d / scale) + (centre - o)/d, g = the fp16 plane
         const f3 r = mk(finite_rcp(rd.x), finite_rcp(rd.y), finite_rcp(rd.z));
@@ -283,8 +283,20 @@ k_render_pw(const RenderArgsBox B)
         for (uint32_t i = threadIdx.x; i < A.n_lds_nodes * 2u; i += THREADS) dst[i] = src[i];
         __syncthreads();
     }
-    // LCG skip-ahead table behind the stacks (and behind the LDS-staged nodes of NODE_FMT 2)
-    uint32_t* const lcg_skip = lds_dyn + (THREADS / 64) * (lds_entries * 64u * ENT) + (NODE_FMT == 2 ? A.n_lds_nodes * 8u : 0u);
+    if (NODE_FMT == 13) {      // experiment: the FIRST 16 bytes of every fp16 node (child 0) staged in LDS, 16 bytes apart; child 1 still comes through the texture path
+        uint4* dst = (uint4*)(lds_dyn + (THREADS / 64) * (lds_entries * 64u));
+        const uint4* src = (const uint4*)sc.hcnodes;
+        for (uint32_t i = threadIdx.x; i < A.n_lds_nodes; i += THREADS) dst[i] = src[2u * i];
+        __syncthreads();
+    }
+    if (NODE_FMT == 14) {      // ... and the whole nodes (32 bytes apart, as in global memory): every node gather from LDS, the texture path sees triangles only
+        uint4* dst = (uint4*)(lds_dyn + (THREADS / 64) * (lds_entries * 64u));
+        const uint4* src = (const uint4*)sc.hcnodes;
+        for (uint32_t i = threadIdx.x; i < A.n_lds_nodes * 2u; i += THREADS) dst[i] = src[i];
+        __syncthreads();
+    }
+    // LCG skip-ahead table behind the stacks (and behind the LDS-staged nodes of NODE_FMT 2 / 13)
+    uint32_t* const lcg_skip = lds_dyn + (THREADS / 64) * (lds_entries * 64u * ENT) + (NODE_FMT == 2 || NODE_FMT == 14 ? A.n_lds_nodes * 8u : NODE_FMT == 13 ? A.n_lds_nodes * 4u : 0u);
     if (threadIdx.x < 32u) { lcg_skip[2u * threadIdx.x] = A.lcg_mul[threadIdx.x]; lcg_skip[2u * threadIdx.x + 1u] = A.lcg_add[threadIdx.x]; }
     const WaveBook book = wave_book(lcg_skip + 64u + wave * kBookDwords, lane);
     // TOPN > 0 (experiment): the first TOPN nodes of the tree, breadth first, staged in LDS behind the books — every ray walks them;
@@ -728,6 +740,19 @@ k_render_pw(const RenderArgsBox B)
                     c0 = (int)qa.w; c1 = (int)qb.w;
                     slab_h9(qa.x, qa.y, qa.z, rinv, gro, rtmin, n0, f0);
                     slab_h9(qb.x, qb.y, qb.z, rinv, gro, rtmin, n1, f1);
+                } else if (NODE_FMT == 14) {
+                    const uint4* np = (const uint4*)((const char*)lds_nodes + (uint32_t)node);
+                    const uint4 qa = np[0], qb = np[1];
+                    c0 = (int)qa.w; c1 = (int)qb.w;
+                    slab_hc(qa.x, qa.y, qa.z, rinv, gro, rtmin, n0, f0);
+                    slab_hc(qb.x, qb.y, qb.z, rinv, gro, rtmin, n1, f1);
+                } else if (NODE_FMT == 13) {
+                    // NODE_FMT 11 with child 0's half of the node from LDS (a node's byte offset halved is its place there), child 1's through the texture path
+                    const uint4 qa = *(const uint4*)((const char*)lds_nodes + ((uint32_t)node >> 1));
+                    const uint4 qb = *(const uint4*)((const char*)sc.hcnodes + (size_t)(uint32_t)node + 16u);
+                    c0 = (int)qa.w; c1 = (int)qb.w;
+                    slab_hc(qa.x, qa.y, qa.z, rinv, gro, rtmin, n0, f0);
+                    slab_hc(qb.x, qb.y, qb.z, rinv, gro, rtmin, n1, f1);
                 } else if (NODE_FMT == 11) {
                     // fp16 centre / half-extent nodes (pt_device.h): no rotates; child references of inner nodes are byte offsets
                     const uint4* np = (const uint4*)((const char*)sc.hcnodes + (size_t)(uint32_t)node);
@@ -1356,6 +1381,8 @@ static size_t variant_lds(const VariantDesc& d, uint32_t stack_entries, uint32_t
     const uint32_t ent = (d.node_fmt == 10 || d.node_fmt == 12) ? 2u : 1u;     // the shared-plane kernel's stack entries are 8 bytes
     size_t lds = (size_t)(d.threads / 64) * (stack_entries * 256u * ent + kBookDwords * 4u) + 256u + (size_t)d.top_n * sizeof(HNode);      // lane stacks, fold bookkeeping, LCG skip-ahead table, staged top of the tree
     if (d.node_fmt == 2) lds += (size_t)n_nodes * sizeof(QNode);
+    if (d.node_fmt == 13) lds += (size_t)n_nodes * 16u;
+    if (d.node_fmt == 14) lds += (size_t)n_nodes * 32u;
     return lds;
 }
 
